@@ -1,0 +1,198 @@
+/* ptgpu.h -- C ABI of the MI355X path-tracing backend (libptgpu.so / libptgpu.a).
+ *
+ * The reference (ArcticXWolf/rust-pathtracer) has no FFI of its own: its seam is the Rust function
+ *   renderer::render(world, camera, width, height, background, samples_per_pixel, max_bounces) -> Vec<u8>
+ * (src/renderer.rs:5-13, one call site at src/main.rs:56-64) over the Hittable / Material / Texture trait
+ * objects.  A GPU backend cannot introspect trait objects, so the host flattens the world into the POD tables
+ * below and hands them over once (the reference builds the world once per run, src/main.rs:23), then renders
+ * frames from it.  Every entry point here cites the reference code whose results it reproduces.
+ *
+ * Conventions: plain C, POD structs with fixed-width fields, no exceptions across the boundary.
+ * Return 0 = success, negative = PtStatus error; the message is available from pt_last_error().
+ * Host pointers are borrowed for the duration of the call only; the library owns all device memory
+ * (except a buffer bound with pt_accum_bind) and frees it in pt_context_destroy().
+ * One context per GPU; one host thread drives a context at a time; contexts are independent.
+ * Calls return after the context's stream has drained.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum PtStatus {
+    PT_OK = 0,
+    PT_ERR_BAD_ARG = -1,     /* null pointer, out-of-range index, malformed scene */
+    PT_ERR_HIP = -2,         /* a HIP runtime call failed (message carries hipGetErrorString) */
+    PT_ERR_OOM = -3,         /* device allocation failed */
+    PT_ERR_NO_SCENE = -4,    /* render / trace before pt_scene_upload */
+    PT_ERR_NO_DEVICE = -5,   /* no usable GPU */
+    PT_ERR_STATE = -6        /* call out of order (e.g. resolve before pt_accum_reset) */
+} PtStatus;
+
+/* ---- primitives: geometry.rs Sphere (:104-171), RectangleXY/XZ/YZ (:182-369), Triangle (:466-589).
+ * An AABox (:371-464) is six consecutive rectangles in the order XY-,XY+,XZ-,XZ+,YZ-,YZ+ referenced as a group.
+ * d[] by type:
+ *   SPHERE    d[0..2] center, d[3] radius (may be negative: hollow glass, normal flips)
+ *   RECT_XY   d[0] plane z, d[1] x_lo, d[2] x_hi, d[3] y_lo, d[4] y_hi, d[5] direction (+1/-1, already signum'd)
+ *   RECT_XZ   d[0] plane y, d[1] x_lo, d[2] x_hi, d[3] z_lo, d[4] z_hi, d[5] direction
+ *   RECT_YZ   d[0] plane x, d[1] y_lo, d[2] y_hi, d[3] z_lo, d[4] z_hi, d[5] direction
+ *   TRIANGLE  d[0..2] point1, d[3..5] point2, d[6..8] point3, d[9..11] stored normal (returned verbatim)
+ * Primitives MUST be listed in the reference's depth-first (left before right, list order inside a group)
+ * order: the index of a primitive in this table is the "hit primitive index" of the parity contract. */
+enum { PT_PRIM_SPHERE = 0, PT_PRIM_RECT_XY = 1, PT_PRIM_RECT_XZ = 2, PT_PRIM_RECT_YZ = 3, PT_PRIM_TRIANGLE = 4 };
+typedef struct PtPrim {
+    uint32_t type;
+    uint32_t material;
+    double d[12];
+} PtPrim;
+
+/* ---- BVH: bvh.rs BvhNode (:57-126).  A child reference is either a node index or, with PT_REF_LEAF set,
+ * a primitive: bits 0..29 = index of the first primitive, PT_REF_GROUP6 set = the six rectangles of an AABox
+ * starting there (scanned in order, geometry.rs:70-83).  A nested ObjModel tree (obj_model.rs:119-121) is
+ * spliced in as an ordinary child node.  Only node boxes are ever tested (bvh.rs:108). */
+#define PT_REF_LEAF 0x80000000u
+#define PT_REF_GROUP6 0x40000000u
+#define PT_REF_INDEX_MASK 0x3FFFFFFFu
+typedef struct PtNode {
+    double bmin[3];
+    double bmax[3];
+    uint32_t left;
+    uint32_t right;
+} PtNode;
+
+/* ---- materials: material.rs Lambertian (:24-56), Metal (:58-94), Dielectric (:96-144), DiffuseLight (:146-167) */
+enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3 };
+typedef struct PtMaterial {
+    uint32_t type;
+    uint32_t texture; /* albedo (lambertian, metal) or emit (diffuse light); ignored for dielectric */
+    double param;     /* metal: fuzz (unclamped); dielectric: index of refraction */
+} PtMaterial;
+
+/* ---- textures: texture.rs SolidColor (:9-23), Checker (:25-45), PerlinNoise marble (:47-81) */
+enum { PT_TEX_SOLID = 0, PT_TEX_CHECKER = 1, PT_TEX_PERLIN = 2 };
+typedef struct PtTexture {
+    uint32_t type;
+    uint32_t odd;          /* checker: texture used where the sine product is < 0 */
+    uint32_t even;         /* checker: texture used otherwise */
+    uint32_t perlin_table; /* perlin: index of a 256-byte permutation in PtSceneDesc.perlin_tables */
+    double color[3];       /* solid */
+    double scale;          /* perlin */
+} PtTexture;
+
+typedef struct PtSceneDesc {
+    const PtNode* nodes;
+    uint32_t n_nodes;
+    uint32_t root; /* child reference of the root (a node for every world BvhNode::new accepts) */
+    const PtPrim* prims;
+    uint32_t n_prims;
+    const PtMaterial* materials;
+    uint32_t n_materials;
+    const PtTexture* textures;
+    uint32_t n_textures;
+    const uint8_t* perlin_tables; /* n_perlin_tables * 256 bytes */
+    uint32_t n_perlin_tables;
+} PtSceneDesc;
+
+/* ---- camera.rs Camera fields (:3-11), as computed by Camera::new (:14-44) on the host */
+typedef struct PtCamera {
+    double origin[3];
+    double lower_left_corner[3];
+    double horizontal[3];
+    double vertical[3];
+    double u[3];
+    double v[3];
+    double lens_radius;
+} PtCamera;
+
+/* ---- result of one BvhNode::hit query (bvh.rs:107-121 -> geometry.rs HitRecord :9-44) */
+typedef struct PtHitOut {
+    int32_t prim;        /* index into PtSceneDesc.prims, -1 = miss */
+    uint32_t front_face; /* geometry.rs:29 */
+    double t;
+    double normal[3];    /* flipped to oppose the ray, geometry.rs:33-37 */
+} PtHitOut;
+
+/* Per-call statistics of pt_render_accumulate.  Kernel times are HIP-event times on the context's stream. */
+typedef struct PtStats {
+    uint64_t rays;            /* hit queries issued (= Ray::color calls with bounces_left > 0, ray.rs:25) */
+    uint64_t paths;           /* primary samples started */
+    uint32_t passes;          /* wavefront passes the call was split into */
+    uint32_t launches_trace;  /* trace kernel launches */
+    uint32_t launches_shade;
+    uint32_t reserved;
+    double ms_total;          /* first launch to last completion */
+    double ms_raygen;
+    double ms_trace;
+    double ms_shade;
+    double ms_fold;
+    uint64_t rays_per_bounce[64]; /* live rays entering bounce b (b >= 64 folded into the last slot) */
+} PtStats;
+
+typedef struct PtContext PtContext;
+
+/* Number of HIP devices visible to the process; negative PtStatus on failure. */
+int pt_device_count(void);
+
+/* Creates a context on `device`: its stream, and nothing else until a scene is uploaded. */
+int pt_context_create(int device, PtContext** out);
+void pt_context_destroy(PtContext* ctx);
+
+/* Message of the last failing call on ctx (or of the last failing pt_context_create when ctx is NULL). */
+const char* pt_last_error(const PtContext* ctx);
+
+/* Options: "paths_per_pass" (upper bound on paths in flight; default 64 Mi),
+ * "profile" (1 = time every kernel with HIP events and fill PtStats.ms_*; default 1). */
+int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
+
+/* Replaces scene.get_world()'s result (scene.rs:38-42): validates and uploads the flattened world.
+ * Errors (PT_ERR_BAD_ARG) mirror the reference's panics: fewer than two objects / empty tree (bvh.rs:76). */
+int pt_scene_upload(PtContext* ctx, const PtSceneDesc* scene);
+
+/* BvhNode::hit (bvh.rs:107-121) for n rays given as host arrays origins[n*3], dirs[n*3]; out[n].
+ * This is the parity entry point: same device traversal code as the render path's trace kernel. */
+int pt_trace_batch(PtContext* ctx, const double* origins, const double* dirs, size_t n, double t_min, double t_max,
+                   PtHitOut* out);
+
+/* Sizes (and zeroes) the accumulation buffer: width*height*3 f32 sums, rows top-first (renderer.rs:14-18). */
+int pt_accum_reset(PtContext* ctx, uint32_t width, uint32_t height);
+
+/* Uses caller-owned device memory (width*height*3 floats on this context's device) as the accumulation
+ * buffer, e.g. a torch tensor that torch.distributed will reduce.  NULL returns to the internal buffer.
+ * Must follow pt_accum_reset; the buffer is NOT cleared by this call. */
+int pt_accum_bind(PtContext* ctx, void* device_ptr);
+
+/* The spp loop of renderer::render (renderer.rs:19-28) for samples [sample_begin, sample_begin+sample_count)
+ * of every pixel: adds each sample's colour to the accumulation buffer.  Sample s of pixel p draws the same
+ * random numbers wherever and whenever it is computed (counter-based RNG keyed by seed, p, s, bounce), so
+ * disjoint sample ranges rendered on different GPUs sum to the single-GPU result.  stats may be NULL. */
+int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width, uint32_t height, const double background[3],
+                         uint32_t sample_begin, uint32_t sample_count, uint32_t max_bounces, uint64_t seed, PtStats* stats);
+
+/* renderer.rs:30-33 + vec3.rs:278-290: sum/total_spp -> sqrt -> (c*255.999) saturating u8; rgb_out = host
+ * buffer of width*height*3 bytes, top row first, RGB. */
+int pt_resolve(PtContext* ctx, uint32_t total_spp, uint8_t* rgb_out);
+
+/* Copies the accumulation buffer to / from host memory (width*height*3 floats). */
+int pt_accum_download(PtContext* ctx, float* rgb_sum);
+int pt_accum_upload(PtContext* ctx, const float* rgb_sum);
+
+/* Device address of the current accumulation buffer (internal or bound); NULL before pt_accum_reset. */
+void* pt_accum_device_ptr(PtContext* ctx);
+
+/* Device-side checks of the arithmetic the parity contract leans on (IEEE division and sqrt, the Philox
+ * stream): computes a[i]/b[i] and sqrt(|a[i]|) on the GPU for host arrays of n doubles. */
+int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root);
+/* First n draws of stream (seed, pixel, sample, stream) as produced on the GPU. */
+int pt_selftest_rng(PtContext* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out);
+/* Texture.value (texture.rs:5-7) of texture `tex` of the uploaded scene at n points (host arrays). */
+int pt_selftest_texture(PtContext* ctx, uint32_t tex, const double* points, size_t n, double* rgb_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

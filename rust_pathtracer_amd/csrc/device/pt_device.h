@@ -1,0 +1,422 @@
+// pt_device.h -- device-side building blocks of the wavefront path tracer (gfx950).
+//
+// All geometry runs in f64 with -ffp-contract=off, in the reference's operand order, so that a hit
+// (primitive index, t, normal) is the same IEEE-754 result the reference computes (rustc never fuses
+// multiply-add; HIP's f64 divide and sqrt expansions are correctly rounded).  Radiometry (throughput,
+// emitted radiance, the accumulation buffer) is f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/ptgpu.h"
+
+#define PT_WAVE 64
+#define PT_BLOCK 256
+#define PT_REJECTION_CAP 256
+
+// ------------------------------------------------------------------ f64 3-vector (vec3.rs)
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }   // vec3.rs:130-136
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }   // :146-152
+__device__ __forceinline__ V3 operator*(V3 a, double t) { return V3{a.x * t, a.y * t, a.z * t}; }     // :178-184
+__device__ __forceinline__ V3 operator*(double t, V3 a) { return V3{a.x * t, a.y * t, a.z * t}; }     // :194-200
+__device__ __forceinline__ V3 operator/(V3 a, double t) { return V3{a.x / t, a.y / t, a.z / t}; }     // :218-224
+__device__ __forceinline__ V3 neg(V3 a) { return V3{a.x * -1.0, a.y * -1.0, a.z * -1.0}; }            // :248-254
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // :87-89
+__device__ __forceinline__ double len_squared(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }     // :83-85
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                      // :91-97
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 unit_vector(V3 a) { return a / sqrt(len_squared(a)); }                   // :99-101
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0 * dot(v, n)) * n; }                // :114-116
+__device__ __forceinline__ V3 refract(V3 v, V3 n, double etai_over_etat) {                              // :118-127
+    double cos_theta = fmin(dot(neg(v), n), 1.0);
+    V3 perp = etai_over_etat * (v + cos_theta * n);
+    V3 parallel = (-sqrt(fabs(1.0 - len_squared(perp)))) * n;
+    return parallel + perp;
+}
+__device__ __forceinline__ bool near_zero(V3 a) {                                                      // :110-112
+    return fabs(a.x) < 1e-8 && fabs(a.y) < 1e-8 && fabs(a.z) < 1e-8;
+}
+
+// ------------------------------------------------------------------ counter-based RNG
+// Philox4x32-10 (Salmon et al., SC'11).  Draw k of stream (pixel, sample, stream) is the 64-bit half k%2 of
+// block k/2 = philox(counter = {pixel, sample, stream, k/2}, key = seed).  Replaces the reference's
+// thread_rng (renderer.rs:23-24, vec3.rs:27-29,35-37,59-60, material.rs:132).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct SampleRng {
+    uint32_t pixel, sample, stream, n, k0, k1;
+    uint32_t cached_block;
+    uint32_t cache[4];
+    __device__ __forceinline__ void init(uint64_t seed, uint32_t pixel_, uint32_t sample_, uint32_t stream_) {
+        pixel = pixel_; sample = sample_; stream = stream_; n = 0;
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        cached_block = 0xFFFFFFFFu;
+        cache[0] = cache[1] = cache[2] = cache[3] = 0;
+    }
+    __device__ __forceinline__ double f64() { // 53 bits in [0,1)
+        uint32_t k = n++;
+        uint32_t block = k >> 1;
+        if (block != cached_block) {
+            philox4x32_10(pixel, sample, stream, block, k0, k1, cache);
+            cached_block = block;
+        }
+        uint32_t lo = (k & 1u) ? cache[2] : cache[0];
+        uint32_t hi = (k & 1u) ? cache[3] : cache[1];
+        uint64_t bits = ((uint64_t)hi << 32) | lo;
+        return (double)(bits >> 11) * (1.0 / 9007199254740992.0);
+    }
+    __device__ __forceinline__ double range(double lo, double hi) { return lo + (hi - lo) * f64(); }
+};
+
+__device__ __forceinline__ V3 random_in_unitsphere(SampleRng& rng) { // vec3.rs:41-49
+    V3 p = v3(0.0, 0.0, 0.0);
+    for (int i = 0; i < PT_REJECTION_CAP; ++i) {
+        double x = rng.range(-1.0, 1.0);
+        double y = rng.range(-1.0, 1.0);
+        double z = rng.range(-1.0, 1.0);
+        p = v3(x, y, z);
+        if (len_squared(p) < 1.0) break;
+    }
+    return p;
+}
+__device__ __forceinline__ V3 random_in_unitdisk_xy(SampleRng& rng) { // vec3.rs:55-67
+    V3 p = v3(0.0, 0.0, 0.0);
+    for (int i = 0; i < PT_REJECTION_CAP; ++i) {
+        double x = rng.range(-1.0, 1.0);
+        double y = rng.range(-1.0, 1.0);
+        p = v3(x, y, 0.0);
+        if (len_squared(p) < 1.0) break;
+    }
+    return p;
+}
+
+// ------------------------------------------------------------------ device scene tables
+struct DevNode { // = PtNode (bvh.rs:57-62); nodes are stored breadth-first so the top levels form a prefix
+    double bmin[3];
+    double bmax[3];
+    uint32_t left, right;
+};
+struct DevPrim { // 80 B: what the hit test reads
+    // sphere: c[3], r | rect: k, a_lo, a_hi, b_lo, b_hi | triangle: point1[3], point2-point1 [3], point3-point1 [3]
+    double d[9];
+    uint32_t type;
+    uint32_t material;
+};
+struct DevScene {
+    const DevNode* nodes;
+    const DevPrim* prims;
+    const double* aux; // 3 per primitive: outward normal of a rectangle / stored normal of a triangle
+    const PtMaterial* materials;
+    const PtTexture* textures;
+    const uint8_t* perlin;
+    uint32_t n_nodes, n_prims, n_materials, n_textures;
+    uint32_t root;
+    uint32_t lds_nodes; // nodes [0, lds_nodes) are staged in LDS by the trace kernel
+    uint32_t lds_prims; // primitives [0, lds_prims) likewise (all of them for small scenes)
+    uint32_t stack_depth;
+};
+
+// ------------------------------------------------------------------ hit tests (t only; the record is rebuilt in shade)
+// Sphere::hit, geometry.rs:132-148
+__device__ __forceinline__ bool hit_sphere(const double* g, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    V3 oc = o - v3(g[0], g[1], g[2]);
+    double a = len_squared(d);
+    double half_b = dot(d, oc);
+    double c = len_squared(oc) - g[3] * g[3];
+    double dis = half_b * half_b - a * c;
+    if (dis < 0.0) return false;
+    double sq = sqrt(dis);
+    double root = (-half_b - sq) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sq) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+// RectangleXY/XZ/YZ::hit, geometry.rs:210-221, :273-284, :336-347.  (on, dn) = ray origin/direction along the
+// plane normal, (oa, da), (ob, db) along the two in-plane axes in the reference's order.
+__device__ __forceinline__ bool hit_rect(const double* g, double on, double dn, double oa, double da, double ob, double db,
+                                         double t_min, double t_max, double& t_out) {
+    double t = (g[0] - on) / dn;
+    if (t < t_min || t > t_max) return false;
+    double a = oa + t * da;
+    double b = ob + t * db;
+    if (a < g[1] || a > g[2] || b < g[3] || b > g[4]) return false;
+    t_out = t;
+    return true;
+}
+// Triangle::hit, geometry.rs:519-546 (Moller-Trumbore, back-face culled at det < 0.0001)
+__device__ __forceinline__ bool hit_triangle(const double* g, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    V3 v0v1 = v3(g[3], g[4], g[5]);
+    V3 v0v2 = v3(g[6], g[7], g[8]);
+    V3 pvec = cross(d, v0v2);
+    double det = dot(v0v1, pvec);
+    if (det < 0.0001) return false;
+    double inv_det = 1.0 / det;
+    V3 tvec = o - v3(g[0], g[1], g[2]);
+    double u = dot(tvec, pvec) * inv_det;
+    if (!(u >= 0.0 && u <= 1.0)) return false;
+    V3 qvec = cross(tvec, v0v1);
+    double v = dot(d, qvec) * inv_det;
+    if (v < 0.0 || u + v > 1.0) return false;
+    double t = dot(v0v2, qvec) * inv_det;
+    if (!(t >= t_min && t <= t_max)) return false;
+    t_out = t;
+    return true;
+}
+__device__ __forceinline__ bool hit_prim(const double* g, uint32_t type, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    switch (type) {
+        case PT_PRIM_SPHERE: return hit_sphere(g, o, d, t_min, t_max, t_out);
+        case PT_PRIM_RECT_XY: return hit_rect(g, o.z, d.z, o.x, d.x, o.y, d.y, t_min, t_max, t_out);
+        case PT_PRIM_RECT_XZ: return hit_rect(g, o.y, d.y, o.x, d.x, o.z, d.z, t_min, t_max, t_out);
+        case PT_PRIM_RECT_YZ: return hit_rect(g, o.x, d.x, o.y, d.y, o.z, d.z, t_min, t_max, t_out);
+        default: return hit_triangle(g, o, d, t_min, t_max, t_out);
+    }
+}
+
+// Aabb::hit, bvh.rs:18-35.  inv = 1/direction is the same value the reference recomputes at every node.
+__device__ __forceinline__ bool hit_aabb(const double* bmin, const double* bmax, V3 o, V3 inv, double t_min, double t_max) {
+    double t0 = (bmin[0] - o.x) * inv.x, t1 = (bmax[0] - o.x) * inv.x;
+    if (inv.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = fmax(t0, t_min);
+    t_max = fmin(t1, t_max);
+    if (t_max <= t_min) return false;
+    t0 = (bmin[1] - o.y) * inv.y; t1 = (bmax[1] - o.y) * inv.y;
+    if (inv.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = fmax(t0, t_min);
+    t_max = fmin(t1, t_max);
+    if (t_max <= t_min) return false;
+    t0 = (bmin[2] - o.z) * inv.z; t1 = (bmax[2] - o.z) * inv.z;
+    if (inv.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+    t_min = fmax(t0, t_min);
+    t_max = fmin(t1, t_max);
+    if (t_max <= t_min) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ BvhNode::hit (bvh.rs:107-121), iteratively
+// The reference recursion (left with t_max, right with t_max shrunk to the left hit, right wins) is a
+// depth-first, left-before-right walk in which every primitive is tested against the closest t found so
+// far and accepted when t <= that bound: the last accepted primitive is the answer.  The walk below keeps
+// that order exactly; pending right children wait on a per-lane stack in LDS (stack[level * blockDim + tid]).
+// lds_nodes / lds_prims point at the staged prefixes of the node and primitive tables.
+// ALL_LDS: the whole scene is staged (small scenes); otherwise only nodes [0, sc.lds_nodes) are.
+template <bool ALL_LDS>
+__device__ __forceinline__ void traverse(const DevScene& sc, const DevNode* lds_nodes, const DevPrim* lds_prims,
+                                         uint32_t* stack, V3 o, V3 d, double t_min, double t_max, double& best_t,
+                                         int32_t& best_prim) {
+    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    best_t = t_max;
+    best_prim = -1;
+    uint32_t sp = 0;
+    uint32_t cur = sc.root;
+    const uint32_t stride = blockDim.x;
+    for (;;) {
+        if (cur & PT_REF_LEAF) {
+            uint32_t first = cur & PT_REF_INDEX_MASK;
+            uint32_t count = (cur & PT_REF_GROUP6) ? 6u : 1u;
+            for (uint32_t k = 0; k < count; ++k) { // geometry.rs:75-80 for a group
+                uint32_t p = first + k;
+                double t;
+                bool h;
+                if (ALL_LDS) {
+                    const DevPrim* pr = lds_prims + p;
+                    h = hit_prim(pr->d, pr->type, o, d, t_min, best_t, t);
+                } else {
+                    const DevPrim* pr = sc.prims + p;
+                    h = hit_prim(pr->d, pr->type, o, d, t_min, best_t, t);
+                }
+                if (h) {
+                    best_t = t;
+                    best_prim = (int32_t)p;
+                }
+            }
+            if (sp == 0) break;
+            cur = stack[(--sp) * stride];
+        } else {
+            double bmin[3], bmax[3];
+            uint32_t left, right;
+            if (ALL_LDS || cur < sc.lds_nodes) {
+                const DevNode* nd = lds_nodes + cur;
+                bmin[0] = nd->bmin[0]; bmin[1] = nd->bmin[1]; bmin[2] = nd->bmin[2];
+                bmax[0] = nd->bmax[0]; bmax[1] = nd->bmax[1]; bmax[2] = nd->bmax[2];
+                left = nd->left; right = nd->right;
+            } else {
+                const DevNode* nd = sc.nodes + cur;
+                bmin[0] = nd->bmin[0]; bmin[1] = nd->bmin[1]; bmin[2] = nd->bmin[2];
+                bmax[0] = nd->bmax[0]; bmax[1] = nd->bmax[1]; bmax[2] = nd->bmax[2];
+                left = nd->left; right = nd->right;
+            }
+            if (hit_aabb(bmin, bmax, o, inv, t_min, best_t)) {
+                stack[sp * stride] = right;
+                ++sp;
+                cur = left;
+            } else {
+                if (sp == 0) break;
+                cur = stack[(--sp) * stride];
+            }
+        }
+    }
+}
+
+// Outward normal of primitive `prim` at point p: geometry.rs:151 (sphere), :227/:290/:353 (rectangles),
+// :554 (triangle: the stored normal).
+__device__ __forceinline__ V3 outward_normal(const DevScene& sc, const DevPrim* pr, uint32_t prim, V3 p) {
+    if (pr->type == PT_PRIM_SPHERE) return (p - v3(pr->d[0], pr->d[1], pr->d[2])) / pr->d[3];
+    const double* a = sc.aux + (size_t)prim * 3;
+    return v3(a[0], a[1], a[2]);
+}
+
+// ------------------------------------------------------------------ textures (texture.rs)
+// noise 0.8.2 Perlin stand-in: improved 3-D Perlin over a 256-entry permutation.
+__device__ __forceinline__ double perlin_grad(int h, double x, double y, double z) {
+    switch (h & 15) {
+        case 0: case 12: return x + y;
+        case 1: case 13: return -x + y;
+        case 2: return x - y;
+        case 3: return -x - y;
+        case 4: return x + z;
+        case 5: return -x + z;
+        case 6: return x - z;
+        case 7: return -x - z;
+        case 8: return y + z;
+        case 9: case 14: return -y + z;
+        case 10: return y - z;
+        default: return -y - z;
+    }
+}
+__device__ __forceinline__ int perlin_hash(const uint8_t* perm, long x, long y, long z) {
+    int a = perm[x & 0xff];
+    int b = perm[a ^ (int)(y & 0xff)];
+    return perm[b ^ (int)(z & 0xff)];
+}
+__device__ __forceinline__ double perlin_quintic(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+__device__ inline double perlin_get(const uint8_t* perm, double px, double py, double pz) {
+    double fx = floor(px), fy = floor(py), fz = floor(pz);
+    long cx = (long)fx, cy = (long)fy, cz = (long)fz;
+    double dx = px - fx, dy = py - fy, dz = pz - fz;
+    double g000 = perlin_grad(perlin_hash(perm, cx, cy, cz), dx, dy, dz);
+    double g100 = perlin_grad(perlin_hash(perm, cx + 1, cy, cz), dx - 1.0, dy, dz);
+    double g010 = perlin_grad(perlin_hash(perm, cx, cy + 1, cz), dx, dy - 1.0, dz);
+    double g110 = perlin_grad(perlin_hash(perm, cx + 1, cy + 1, cz), dx - 1.0, dy - 1.0, dz);
+    double g001 = perlin_grad(perlin_hash(perm, cx, cy, cz + 1), dx, dy, dz - 1.0);
+    double g101 = perlin_grad(perlin_hash(perm, cx + 1, cy, cz + 1), dx - 1.0, dy, dz - 1.0);
+    double g011 = perlin_grad(perlin_hash(perm, cx, cy + 1, cz + 1), dx, dy - 1.0, dz - 1.0);
+    double g111 = perlin_grad(perlin_hash(perm, cx + 1, cy + 1, cz + 1), dx - 1.0, dy - 1.0, dz - 1.0);
+    double u = perlin_quintic(dx), v = perlin_quintic(dy), w = perlin_quintic(dz);
+    double k0 = g000;
+    double k1 = g100 - g000;
+    double k2 = g010 - g000;
+    double k3 = g001 - g000;
+    double k4 = g000 + g110 - g100 - g010;
+    double k5 = g000 + g101 - g100 - g001;
+    double k6 = g000 + g011 - g010 - g001;
+    double k7 = g100 + g010 + g001 + g111 - g000 - g110 - g101 - g011;
+    double r = k0 + k1 * u + k2 * v + k3 * w + k4 * u * v + k5 * u * w + k6 * v * w + k7 * u * v * w;
+    r = r * 1.1547005383792515;
+    if (r < -1.0) r = -1.0;
+    if (r > 1.0) r = 1.0;
+    return r;
+}
+// Texture::value (texture.rs:19-23, :36-45, :75-80); u,v are unused by every texture the reference ships.
+__device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 p) {
+    for (uint32_t guard = 0; guard <= sc.n_textures; ++guard) {
+        const PtTexture* t = sc.textures + tex;
+        if (t->type == PT_TEX_CHECKER) {
+            double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
+            tex = (sines < 0.0) ? t->odd : t->even;
+            continue;
+        }
+        if (t->type == PT_TEX_SOLID) return v3(t->color[0], t->color[1], t->color[2]);
+        // marble: texture.rs:60-80, 7 octaves
+        const uint8_t* perm = sc.perlin + (size_t)t->perlin_table * 256;
+        double accumulator = 0.0, weight = 1.0;
+        double qx = p.x, qy = p.y, qz = p.z;
+        for (int i = 0; i < 7; ++i) {
+            accumulator += weight * perlin_get(perm, qx, qy, qz);
+            weight *= 0.5;
+            qx *= 2.0; qy *= 2.0; qz *= 2.0;
+        }
+        double turb = fabs(accumulator);
+        double c = 0.5 * (1.0 - sin(t->scale * p.z + 10.0 * turb));
+        return v3(1.0 * c, 1.0 * c, 1.0 * c);
+    }
+    return v3(0.0, 0.0, 0.0);
+}
+
+// ------------------------------------------------------------------ materials (material.rs)
+// f64::powi(5) as compiler-rt's __powidf2 evaluates it: x * ((x*x)*(x*x)).
+__device__ __forceinline__ double reflectance(double cosine, double refraction_index) { // material.rs:109-113
+    double q = (1.0 - refraction_index) / (1.0 + refraction_index);
+    double r0 = q * q;
+    double m = 1.0 - cosine;
+    double m2 = m * m;
+    double m4 = m2 * m2;
+    return r0 + (1.0 - r0) * (m * m4);
+}
+
+// Material::scatter for the hit (point p, unit-or-not normal n already flipped to oppose the ray).
+// Returns false when the path ends (no scatter).  attenuation is evaluated by the caller via texture_value.
+__device__ __forceinline__ bool scatter(const PtMaterial& m, V3 ray_d, V3 n, bool front_face, SampleRng& rng, V3& out_d,
+                                        bool& textured) {
+    switch (m.type) {
+        case PT_MAT_LAMBERTIAN: { // material.rs:41-55
+            V3 dir = n + unit_vector(random_in_unitsphere(rng));
+            if (near_zero(dir)) dir = n;
+            out_d = dir;
+            textured = true;
+            return true;
+        }
+        case PT_MAT_METAL: { // material.rs:77-93
+            V3 reflected = reflect(unit_vector(ray_d), n);
+            if (dot(reflected, n) > 0.0) {
+                out_d = reflected + m.param * random_in_unitsphere(rng);
+                textured = true;
+                return true;
+            }
+            return false;
+        }
+        case PT_MAT_DIELECTRIC: { // material.rs:117-143
+            double refraction_ratio = front_face ? 1.0 / m.param : m.param;
+            V3 unit_direction = unit_vector(ray_d);
+            double cos_theta = fmin(dot(neg(unit_direction), n), 1.0);
+            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+            bool reflects = (refraction_ratio * sin_theta > 1.0);
+            if (!reflects) reflects = reflectance(cos_theta, refraction_ratio) > rng.f64();
+            out_d = reflects ? reflect(unit_direction, n) : refract(unit_direction, n, refraction_ratio);
+            textured = false; // attenuation (1,1,1)
+            return true;
+        }
+        default: // DiffuseLight never scatters (material.rs:16-18)
+            return false;
+    }
+}
+
+// ------------------------------------------------------------------ stream layouts
+// Rays live in HBM as three double2 streams (16 B per lane per access): (ox,oy) (oz,dx) (dy,dz).
+struct RayStream {
+    double2* a;
+    double2* b;
+    double2* c;
+};
+// Path state: x = path slot within the pass (sample_slot * npix + pixel), yzw = throughput as f32 bits.
+// Hits: t (f64) and primitive (i32, -1 = miss).

@@ -1,0 +1,696 @@
+// ptgpu.hip -- implementation of the C ABI in include/ptgpu.h: context, scene upload, the wavefront driver.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pt_launch.h"
+
+namespace {
+thread_local std::string g_last_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+}  // namespace
+
+struct PtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int cu_count = 256;
+
+    // scene
+    bool has_scene = false;
+    DevScene sc{};
+    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin;
+    LaunchGeom geom{};
+
+    // accumulation
+    uint32_t width = 0, height = 0;
+    DevBuf d_accum_own;
+    float* d_accum = nullptr;
+    DevBuf d_rgb;
+
+    // wavefront streams
+    size_t wf_capacity = 0;
+    uint32_t counts_cap = 0;
+    Wavefront wf{};
+    std::vector<DevBuf> wf_bufs;
+
+    // options
+    int64_t paths_per_pass = (int64_t)1 << 25;
+    int profile = 1;
+    std::vector<hipEvent_t> events;
+
+    int fail(int code, const std::string& msg) {
+        err = msg;
+        g_last_error = msg;
+        return code;
+    }
+    int fail_hip(const char* what, hipError_t e) {
+        return fail(e == hipErrorOutOfMemory ? PT_ERR_OOM : PT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+};
+
+#define PT_HIP(ctx, call)                                       \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return (ctx)->fail_hip(#call, e_); \
+    } while (0)
+
+namespace {
+
+void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+hipError_t ensure_buf(DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return hipSuccess;
+    free_buf(b);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e == hipSuccess) b.bytes = bytes;
+    return e;
+}
+
+void free_wavefront(PtContext* ctx) {
+    for (auto& b : ctx->wf_bufs) free_buf(b);
+    ctx->wf_bufs.clear();
+    ctx->wf = Wavefront{};
+    ctx->wf_capacity = 0;
+    ctx->counts_cap = 0;
+}
+
+int ensure_wavefront(PtContext* ctx, size_t capacity, uint32_t n_counts) {
+    if (ctx->wf_capacity >= capacity && ctx->counts_cap >= n_counts) return PT_OK;
+    free_wavefront(ctx);
+    const size_t sizes[] = {
+        capacity * sizeof(double2), capacity * sizeof(double2), capacity * sizeof(double2),  // rays[0]
+        capacity * sizeof(double2), capacity * sizeof(double2), capacity * sizeof(double2),  // rays[1]
+        capacity * sizeof(uint4),   capacity * sizeof(uint4),                               // state
+        capacity * sizeof(double),  capacity * sizeof(int32_t),                             // hits
+        capacity * sizeof(float4),                                                          // plane
+        (size_t)n_counts * sizeof(uint32_t), (size_t)n_counts * sizeof(unsigned long long)  // counts, totals
+    };
+    const size_t nb = sizeof(sizes) / sizeof(sizes[0]);
+    ctx->wf_bufs.resize(nb);
+    for (size_t i = 0; i < nb; ++i) {
+        hipError_t e = ensure_buf(ctx->wf_bufs[i], sizes[i]);
+        if (e != hipSuccess) {
+            free_wavefront(ctx);
+            return ctx->fail_hip("hipMalloc(wavefront streams)", e);
+        }
+    }
+    Wavefront& w = ctx->wf;
+    w.rays[0] = RayStream{(double2*)ctx->wf_bufs[0].p, (double2*)ctx->wf_bufs[1].p, (double2*)ctx->wf_bufs[2].p};
+    w.rays[1] = RayStream{(double2*)ctx->wf_bufs[3].p, (double2*)ctx->wf_bufs[4].p, (double2*)ctx->wf_bufs[5].p};
+    w.state[0] = (uint4*)ctx->wf_bufs[6].p;
+    w.state[1] = (uint4*)ctx->wf_bufs[7].p;
+    w.hit_t = (double*)ctx->wf_bufs[8].p;
+    w.hit_prim = (int32_t*)ctx->wf_bufs[9].p;
+    w.plane = (float4*)ctx->wf_bufs[10].p;
+    w.counts = (uint32_t*)ctx->wf_bufs[11].p;
+    w.totals = (unsigned long long*)ctx->wf_bufs[12].p;
+    ctx->wf_capacity = capacity;
+    ctx->counts_cap = n_counts;
+    return PT_OK;
+}
+
+// Walks the tree the way the reference recursion does, checking that it is a tree over valid indices and
+// that the primitives appear in depth-first order.  Returns the deepest nesting of nodes.
+struct TreeCheck {
+    const PtSceneDesc* s;
+    std::vector<uint8_t> seen;
+    uint32_t next_prim = 0;
+    uint32_t max_depth = 0;
+    std::string error;
+    bool walk() {
+        // explicit stack: (ref, depth); children pushed right first so the left is visited first
+        std::vector<std::pair<uint32_t, uint32_t>> st;
+        st.emplace_back(s->root, 1u);
+        while (!st.empty()) {
+            auto [ref, depth] = st.back();
+            st.pop_back();
+            if (ref & PT_REF_LEAF) {
+                uint32_t first = ref & PT_REF_INDEX_MASK;
+                uint32_t count = (ref & PT_REF_GROUP6) ? 6u : 1u;
+                if (first != next_prim) {
+                    error = "primitives are not listed in depth-first order";
+                    return false;
+                }
+                if ((uint64_t)first + count > s->n_prims) {
+                    error = "leaf reference past the primitive table";
+                    return false;
+                }
+                if (count == 6u) {
+                    for (uint32_t k = 0; k < 6; ++k) {
+                        uint32_t t = s->prims[first + k].type;
+                        if (t != PT_PRIM_RECT_XY && t != PT_PRIM_RECT_XZ && t != PT_PRIM_RECT_YZ) {
+                            error = "a group of six must hold rectangles (AABox sides)";
+                            return false;
+                        }
+                    }
+                }
+                next_prim = first + count;
+                continue;
+            }
+            if (ref >= s->n_nodes) {
+                error = "node reference out of range";
+                return false;
+            }
+            if (seen[ref]) {
+                error = "node referenced twice: not a tree";
+                return false;
+            }
+            seen[ref] = 1;
+            max_depth = std::max(max_depth, depth);
+            st.emplace_back(s->nodes[ref].right, depth + 1);
+            st.emplace_back(s->nodes[ref].left, depth + 1);
+        }
+        if (next_prim != s->n_prims) {
+            error = "tree does not reference every primitive";
+            return false;
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int pt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return e == hipErrorNoDevice ? 0 : PT_ERR_HIP;
+    }
+    return n;
+}
+
+int pt_context_create(int device, PtContext** out) {
+    if (!out) {
+        g_last_error = "pt_context_create: out is NULL";
+        return PT_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    int n = pt_device_count();
+    if (n <= 0) {
+        if (n == 0) g_last_error = "no HIP device visible";
+        return PT_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_last_error = "pt_context_create: device index out of range";
+        return PT_ERR_BAD_ARG;
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return PT_ERR_HIP;
+    }
+    PtContext* ctx = new PtContext();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return PT_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
+    *out = ctx;
+    return PT_OK;
+}
+
+void pt_context_destroy(PtContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
+    free_wavefront(ctx);
+    free_buf(ctx->d_nodes);
+    free_buf(ctx->d_prims);
+    free_buf(ctx->d_aux);
+    free_buf(ctx->d_mats);
+    free_buf(ctx->d_texs);
+    free_buf(ctx->d_perlin);
+    free_buf(ctx->d_accum_own);
+    free_buf(ctx->d_rgb);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* pt_last_error(const PtContext* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return PT_ERR_BAD_ARG;
+    std::string k(key);
+    if (k == "paths_per_pass") {
+        if (value < 1 || value > ((int64_t)1 << 31)) return ctx->fail(PT_ERR_BAD_ARG, "paths_per_pass out of range [1, 2^31]");
+        ctx->paths_per_pass = value;
+    } else if (k == "profile") {
+        ctx->profile = value ? 1 : 0;
+    } else {
+        return ctx->fail(PT_ERR_BAD_ARG, "unknown option " + k);
+    }
+    return PT_OK;
+}
+
+int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!s || !s->nodes || !s->prims || !s->materials) return ctx->fail(PT_ERR_BAD_ARG, "pt_scene_upload: null table");
+    // bvh.rs:76: BvhNode::new panics on fewer than two objects, so every world has a root node
+    if (s->n_nodes < 1 || s->n_prims < 2) return ctx->fail(PT_ERR_BAD_ARG, "creating BVH node from empty object list");
+    if (s->n_prims > PT_REF_INDEX_MASK || s->n_nodes > PT_REF_INDEX_MASK) return ctx->fail(PT_ERR_BAD_ARG, "scene too large");
+    if (s->root & PT_REF_LEAF) return ctx->fail(PT_ERR_BAD_ARG, "root must be a node");
+    if (s->n_materials < 1) return ctx->fail(PT_ERR_BAD_ARG, "no materials");
+    if (s->n_textures > 0 && !s->textures) return ctx->fail(PT_ERR_BAD_ARG, "null texture table");
+    if (s->n_perlin_tables > 0 && !s->perlin_tables) return ctx->fail(PT_ERR_BAD_ARG, "null perlin tables");
+
+    TreeCheck tc{s, std::vector<uint8_t>(s->n_nodes, 0)};
+    if (!tc.walk()) return ctx->fail(PT_ERR_BAD_ARG, "pt_scene_upload: " + tc.error);
+    for (uint32_t i = 0; i < s->n_nodes; ++i)
+        if (!tc.seen[i]) return ctx->fail(PT_ERR_BAD_ARG, "pt_scene_upload: unreachable node");
+    if (tc.max_depth > 56) return ctx->fail(PT_ERR_BAD_ARG, "pt_scene_upload: tree deeper than 56 levels");
+
+    // textures: types, children, and no cycles among checkers
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const PtTexture& t = s->textures[i];
+        if (t.type > PT_TEX_PERLIN) return ctx->fail(PT_ERR_BAD_ARG, "bad texture type");
+        if (t.type == PT_TEX_CHECKER && (t.odd >= s->n_textures || t.even >= s->n_textures))
+            return ctx->fail(PT_ERR_BAD_ARG, "checker child out of range");
+        if (t.type == PT_TEX_PERLIN && t.perlin_table >= s->n_perlin_tables)
+            return ctx->fail(PT_ERR_BAD_ARG, "perlin table out of range");
+    }
+    {
+        std::vector<int> state(s->n_textures, 0);  // 0 new, 1 on path, 2 done
+        for (uint32_t root = 0; root < s->n_textures; ++root) {
+            if (state[root]) continue;
+            std::vector<std::pair<uint32_t, int>> st{{root, 0}};
+            state[root] = 1;
+            while (!st.empty()) {
+                auto& [t, step] = st.back();
+                const PtTexture& tx = s->textures[t];
+                if (tx.type != PT_TEX_CHECKER || step == 2) {
+                    state[t] = 2;
+                    st.pop_back();
+                    continue;
+                }
+                uint32_t child = step == 0 ? tx.odd : tx.even;
+                ++step;
+                if (state[child] == 1) return ctx->fail(PT_ERR_BAD_ARG, "texture graph has a cycle");
+                if (state[child] == 0) {
+                    state[child] = 1;
+                    st.emplace_back(child, 0);
+                }
+            }
+        }
+    }
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const PtMaterial& m = s->materials[i];
+        if (m.type > PT_MAT_DIFFUSE_LIGHT) return ctx->fail(PT_ERR_BAD_ARG, "bad material type");
+        if (m.type != PT_MAT_DIELECTRIC && m.texture >= s->n_textures) return ctx->fail(PT_ERR_BAD_ARG, "material texture out of range");
+    }
+
+    // device primitive records
+    std::vector<DevPrim> prims(s->n_prims);
+    std::vector<double> aux((size_t)s->n_prims * 3, 0.0);
+    for (uint32_t i = 0; i < s->n_prims; ++i) {
+        const PtPrim& p = s->prims[i];
+        DevPrim& q = prims[i];
+        std::memset(&q, 0, sizeof(q));
+        if (p.material >= s->n_materials) return ctx->fail(PT_ERR_BAD_ARG, "primitive material out of range");
+        q.type = p.type;
+        q.material = p.material;
+        switch (p.type) {
+            case PT_PRIM_SPHERE:
+                for (int k = 0; k < 4; ++k) q.d[k] = p.d[k];
+                break;
+            case PT_PRIM_RECT_XY:
+            case PT_PRIM_RECT_XZ:
+            case PT_PRIM_RECT_YZ: {
+                for (int k = 0; k < 5; ++k) q.d[k] = p.d[k];
+                int axis = p.type == PT_PRIM_RECT_XY ? 2 : (p.type == PT_PRIM_RECT_XZ ? 1 : 0);
+                aux[(size_t)i * 3 + axis] = p.d[5];  // geometry.rs:227 / :290 / :353
+                break;
+            }
+            case PT_PRIM_TRIANGLE:
+                for (int k = 0; k < 3; ++k) {
+                    q.d[k] = p.d[k];
+                    q.d[3 + k] = p.d[3 + k] - p.d[k];  // point2 - point1, geometry.rs:521
+                    q.d[6 + k] = p.d[6 + k] - p.d[k];  // point3 - point1, geometry.rs:522
+                    aux[(size_t)i * 3 + k] = p.d[9 + k];
+                }
+                break;
+            default:
+                return ctx->fail(PT_ERR_BAD_ARG, "bad primitive type");
+        }
+    }
+
+    // breadth-first renumbering: the top levels become a prefix of the node table (staged in LDS by trace)
+    std::vector<uint32_t> order;  // order[new] = old
+    order.reserve(s->n_nodes);
+    std::vector<uint32_t> remap(s->n_nodes, 0);
+    order.push_back(s->root);
+    for (size_t head = 0; head < order.size(); ++head) {
+        const PtNode& nd = s->nodes[order[head]];
+        if (!(nd.left & PT_REF_LEAF)) order.push_back(nd.left);
+        if (!(nd.right & PT_REF_LEAF)) order.push_back(nd.right);
+    }
+    for (uint32_t i = 0; i < (uint32_t)order.size(); ++i) remap[order[i]] = i;
+    std::vector<DevNode> nodes(s->n_nodes);
+    for (uint32_t i = 0; i < s->n_nodes; ++i) {
+        const PtNode& src = s->nodes[order[i]];
+        DevNode& dst = nodes[i];
+        for (int k = 0; k < 3; ++k) {
+            dst.bmin[k] = src.bmin[k];
+            dst.bmax[k] = src.bmax[k];
+        }
+        dst.left = (src.left & PT_REF_LEAF) ? src.left : remap[src.left];
+        dst.right = (src.right & PT_REF_LEAF) ? src.right : remap[src.right];
+    }
+
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_scene = false;
+    PT_HIP(ctx, ensure_buf(ctx->d_nodes, nodes.size() * sizeof(DevNode)));
+    PT_HIP(ctx, ensure_buf(ctx->d_prims, prims.size() * sizeof(DevPrim)));
+    PT_HIP(ctx, ensure_buf(ctx->d_aux, aux.size() * sizeof(double)));
+    PT_HIP(ctx, ensure_buf(ctx->d_mats, (size_t)s->n_materials * sizeof(PtMaterial)));
+    PT_HIP(ctx, ensure_buf(ctx->d_texs, std::max<size_t>(1, s->n_textures) * sizeof(PtTexture)));
+    PT_HIP(ctx, ensure_buf(ctx->d_perlin, std::max<size_t>(1, s->n_perlin_tables) * 256));
+    PT_HIP(ctx, hipMemcpy(ctx->d_nodes.p, nodes.data(), nodes.size() * sizeof(DevNode), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_prims.p, prims.data(), prims.size() * sizeof(DevPrim), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_aux.p, aux.data(), aux.size() * sizeof(double), hipMemcpyHostToDevice));
+    PT_HIP(ctx, hipMemcpy(ctx->d_mats.p, s->materials, (size_t)s->n_materials * sizeof(PtMaterial), hipMemcpyHostToDevice));
+    if (s->n_textures)
+        PT_HIP(ctx, hipMemcpy(ctx->d_texs.p, s->textures, (size_t)s->n_textures * sizeof(PtTexture), hipMemcpyHostToDevice));
+    if (s->n_perlin_tables)
+        PT_HIP(ctx, hipMemcpy(ctx->d_perlin.p, s->perlin_tables, (size_t)s->n_perlin_tables * 256, hipMemcpyHostToDevice));
+
+    DevScene& sc = ctx->sc;
+    sc.nodes = (const DevNode*)ctx->d_nodes.p;
+    sc.prims = (const DevPrim*)ctx->d_prims.p;
+    sc.aux = (const double*)ctx->d_aux.p;
+    sc.materials = (const PtMaterial*)ctx->d_mats.p;
+    sc.textures = (const PtTexture*)ctx->d_texs.p;
+    sc.perlin = (const uint8_t*)ctx->d_perlin.p;
+    sc.n_nodes = s->n_nodes;
+    sc.n_prims = s->n_prims;
+    sc.n_materials = s->n_materials;
+    sc.n_textures = s->n_textures;
+    sc.root = 0;  // the root is first in breadth-first order
+    sc.stack_depth = tc.max_depth;
+
+    // LDS plan for the trace kernel: [staged nodes][staged primitives][per-lane stack]
+    const size_t stack_bytes = (size_t)sc.stack_depth * PT_BLOCK * sizeof(uint32_t);
+    const size_t scene_bytes = (size_t)s->n_nodes * sizeof(DevNode) + (size_t)s->n_prims * sizeof(DevPrim);
+    const size_t lds_limit = 64 * 1024;
+    LaunchGeom& g = ctx->geom;
+    if (scene_bytes + stack_bytes <= 40 * 1024) {
+        g.all_lds = true;
+        sc.lds_nodes = s->n_nodes;
+        sc.lds_prims = s->n_prims;
+    } else {
+        g.all_lds = false;
+        size_t room = lds_limit > stack_bytes ? (lds_limit - stack_bytes) / 2 : 0;  // half the remainder: keep 2+ blocks/CU
+        sc.lds_nodes = (uint32_t)std::min<size_t>(s->n_nodes, room / sizeof(DevNode));
+        sc.lds_prims = 0;
+    }
+    g.trace_lds_bytes = (size_t)sc.lds_nodes * sizeof(DevNode) + (size_t)sc.lds_prims * sizeof(DevPrim) + stack_bytes;
+    g.grid = (uint32_t)ctx->cu_count * 8u;
+    ctx->has_scene = true;
+    return PT_OK;
+}
+
+int pt_trace_batch(PtContext* ctx, const double* origins, const double* dirs, size_t n, double t_min, double t_max,
+                   PtHitOut* out) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_trace_batch: no scene uploaded");
+    if (n == 0) return PT_OK;
+    if (!origins || !dirs || !out) return ctx->fail(PT_ERR_BAD_ARG, "pt_trace_batch: null array");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t chunk_max = (size_t)1 << 22;
+    const size_t cap = std::min(n, chunk_max);
+    DevBuf d_o, d_d, d_out;
+    hipError_t e = ensure_buf(d_o, cap * 3 * sizeof(double));
+    if (e == hipSuccess) e = ensure_buf(d_d, cap * 3 * sizeof(double));
+    if (e == hipSuccess) e = ensure_buf(d_out, cap * sizeof(PtHitOut));
+    int rc = PT_OK;
+    if (e != hipSuccess) rc = ctx->fail_hip("hipMalloc(trace batch)", e);
+    for (size_t done = 0; rc == PT_OK && done < n; done += chunk_max) {
+        const size_t m = std::min(chunk_max, n - done);
+        e = hipMemcpyAsync(d_o.p, origins + done * 3, m * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_d.p, dirs + done * 3, m * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            launch_trace_batch(ctx->stream, ctx->geom, ctx->sc, (const double*)d_o.p, (const double*)d_d.p, (uint32_t)m, t_min, t_max,
+                               (PtHitOut*)d_out.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(out + done, d_out.p, m * sizeof(PtHitOut), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = ctx->fail_hip("pt_trace_batch", e);
+    }
+    free_buf(d_o);
+    free_buf(d_d);
+    free_buf(d_out);
+    return rc;
+}
+
+int pt_accum_reset(PtContext* ctx, uint32_t width, uint32_t height) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (width < 2 || height < 2) return ctx->fail(PT_ERR_BAD_ARG, "pt_accum_reset: width and height must be >= 2");  // (w-1), (h-1) divide
+    if ((uint64_t)width * height > ((uint64_t)1 << 28)) return ctx->fail(PT_ERR_BAD_ARG, "pt_accum_reset: image too large");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+    PT_HIP(ctx, ensure_buf(ctx->d_accum_own, bytes));
+    PT_HIP(ctx, ensure_buf(ctx->d_rgb, (size_t)width * height * 3));
+    ctx->d_accum = (float*)ctx->d_accum_own.p;
+    ctx->width = width;
+    ctx->height = height;
+    PT_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, bytes, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_accum_bind(PtContext* ctx, void* device_ptr) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (ctx->width == 0) return ctx->fail(PT_ERR_STATE, "pt_accum_bind before pt_accum_reset");
+    ctx->d_accum = device_ptr ? (float*)device_ptr : (float*)ctx->d_accum_own.p;
+    return PT_OK;
+}
+
+void* pt_accum_device_ptr(PtContext* ctx) { return ctx ? (void*)ctx->d_accum : nullptr; }
+
+int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width, uint32_t height, const double background[3],
+                         uint32_t sample_begin, uint32_t sample_count, uint32_t max_bounces, uint64_t seed, PtStats* stats) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_render_accumulate: no scene uploaded");
+    if (!camera || !background) return ctx->fail(PT_ERR_BAD_ARG, "pt_render_accumulate: null argument");
+    if (ctx->width == 0 || !ctx->d_accum) return ctx->fail(PT_ERR_STATE, "pt_render_accumulate before pt_accum_reset");
+    if (width != ctx->width || height != ctx->height)
+        return ctx->fail(PT_ERR_BAD_ARG, "pt_render_accumulate: size differs from pt_accum_reset");
+    if (max_bounces > 4096) return ctx->fail(PT_ERR_BAD_ARG, "pt_render_accumulate: max_bounces > 4096");
+    if ((uint64_t)sample_begin + sample_count > 0xFFFFFFFFull) return ctx->fail(PT_ERR_BAD_ARG, "sample range overflows 32 bits");
+    if (sample_count == 0 || max_bounces == 0) return PT_OK;  // ray.rs:21-23: depth 0 contributes black
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+
+    const uint32_t npix = width * height;
+    uint64_t slots64 = std::max<uint64_t>(1, (uint64_t)ctx->paths_per_pass / npix);
+    slots64 = std::min<uint64_t>(slots64, sample_count);
+    slots64 = std::min<uint64_t>(slots64, 0xFFFFFFFFull / npix);
+    const uint32_t slots = (uint32_t)slots64;
+    const uint32_t n_counts = max_bounces + 2;
+    int rc = ensure_wavefront(ctx, (size_t)slots * npix, n_counts);
+    if (rc != PT_OK) return rc;
+
+    PassParams p{};
+    p.width = width;
+    p.height = height;
+    p.npix = npix;
+    p.max_bounces = max_bounces;
+    p.seed = seed;
+    for (int k = 0; k < 3; ++k) p.bg[k] = (float)background[k];
+    p.tiled = (width % 8 == 0 && height % 8 == 0) ? 1 : 0;
+
+    // event bookkeeping: ev[k] separates launch k-1 from launch k; kinds[k] = what ran between ev[k] and ev[k+1]
+    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_GAP = 4 };
+    std::vector<int> kinds;
+    size_t ev_used = 0;
+    auto mark = [&](int kind_after) -> hipError_t {
+        if (!ctx->profile) return hipSuccess;
+        if (ev_used == ctx->events.size()) {
+            hipEvent_t ev;
+            hipError_t e = hipEventCreate(&ev);
+            if (e != hipSuccess) return e;
+            ctx->events.push_back(ev);
+        }
+        kinds.push_back(kind_after);
+        return hipEventRecord(ctx->events[ev_used++], ctx->stream);
+    };
+
+    PT_HIP(ctx, hipMemsetAsync(ctx->wf.totals, 0, (size_t)n_counts * sizeof(unsigned long long), ctx->stream));
+    uint32_t passes = 0, launches_trace = 0, launches_shade = 0;
+    for (uint32_t done = 0; done < sample_count; done += slots) {
+        const uint32_t cur = std::min(slots, sample_count - done);
+        p.n_paths = cur * npix;
+        p.sample_base = sample_begin + done;
+        PT_HIP(ctx, hipMemsetAsync(ctx->wf.counts, 0, (size_t)n_counts * sizeof(uint32_t), ctx->stream));
+        PT_HIP(ctx, mark(K_RAYGEN));
+        launch_raygen(ctx->stream, ctx->geom, *camera, p, ctx->wf);
+        for (uint32_t b = 0; b < max_bounces; ++b) {
+            PT_HIP(ctx, mark(K_TRACE));
+            launch_trace(ctx->stream, ctx->geom, ctx->sc, ctx->wf, b);
+            PT_HIP(ctx, mark(K_SHADE));
+            launch_shade(ctx->stream, ctx->geom, ctx->sc, p, ctx->wf, b);
+            ++launches_trace;
+            ++launches_shade;
+        }
+        PT_HIP(ctx, mark(K_FOLD));
+        launch_fold(ctx->stream, p, ctx->wf, cur, ctx->d_accum);
+        PT_HIP(ctx, mark(K_GAP));
+        launch_count_totals(ctx->stream, ctx->wf, n_counts);
+        PT_HIP(ctx, hipGetLastError());
+        ++passes;
+    }
+    PT_HIP(ctx, mark(K_GAP));
+    std::vector<unsigned long long> totals(n_counts, 0);
+    PT_HIP(ctx, hipMemcpyAsync(totals.data(), ctx->wf.totals, (size_t)n_counts * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    if (stats) {
+        stats->paths = (uint64_t)npix * sample_count;
+        stats->passes = passes;
+        stats->launches_trace = launches_trace;
+        stats->launches_shade = launches_shade;
+        for (uint32_t b = 0; b < max_bounces; ++b) {
+            stats->rays += totals[b];
+            stats->rays_per_bounce[std::min<uint32_t>(b, 63)] += totals[b];
+        }
+        if (ctx->profile && ev_used >= 2) {
+            float ms = 0.f;
+            PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[0], ctx->events[ev_used - 1]));
+            stats->ms_total = ms;
+            for (size_t k = 0; k + 1 < ev_used; ++k) {
+                PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
+                switch (kinds[k]) {
+                    case K_RAYGEN: stats->ms_raygen += ms; break;
+                    case K_TRACE: stats->ms_trace += ms; break;
+                    case K_SHADE: stats->ms_shade += ms; break;
+                    case K_FOLD: stats->ms_fold += ms; break;
+                    default: break;
+                }
+            }
+        }
+    }
+    return PT_OK;
+}
+
+int pt_resolve(PtContext* ctx, uint32_t total_spp, uint8_t* rgb_out) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (ctx->width == 0 || !ctx->d_accum) return ctx->fail(PT_ERR_STATE, "pt_resolve before pt_accum_reset");
+    if (!rgb_out || total_spp == 0) return ctx->fail(PT_ERR_BAD_ARG, "pt_resolve: null output or zero spp");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = ctx->width * ctx->height * 3;
+    launch_resolve(ctx->stream, ctx->d_accum, n, total_spp, (uint8_t*)ctx->d_rgb.p);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(rgb_out, ctx->d_rgb.p, n, hipMemcpyDeviceToHost, ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_accum_download(PtContext* ctx, float* rgb_sum) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (ctx->width == 0 || !ctx->d_accum) return ctx->fail(PT_ERR_STATE, "pt_accum_download before pt_accum_reset");
+    if (!rgb_sum) return ctx->fail(PT_ERR_BAD_ARG, "pt_accum_download: null output");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipMemcpyAsync(rgb_sum, ctx->d_accum, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_accum_upload(PtContext* ctx, const float* rgb_sum) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (ctx->width == 0 || !ctx->d_accum) return ctx->fail(PT_ERR_STATE, "pt_accum_upload before pt_accum_reset");
+    if (!rgb_sum) return ctx->fail(PT_ERR_BAD_ARG, "pt_accum_upload: null input");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    PT_HIP(ctx, hipMemcpyAsync(ctx->d_accum, rgb_sum, (size_t)ctx->width * ctx->height * 3 * sizeof(float), hipMemcpyHostToDevice,
+                               ctx->stream));
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PT_OK;
+}
+
+int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!a || !b || !quot || !root || n == 0 || n > ((size_t)1 << 26)) return ctx->fail(PT_ERR_BAD_ARG, "pt_selftest_arith: bad argument");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf da, db, dq, dr;
+    hipError_t e = ensure_buf(da, n * 8);
+    if (e == hipSuccess) e = ensure_buf(db, n * 8);
+    if (e == hipSuccess) e = ensure_buf(dq, n * 8);
+    if (e == hipSuccess) e = ensure_buf(dr, n * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(da.p, a, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db.p, b, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        launch_selftest_arith(ctx->stream, (const double*)da.p, (const double*)db.p, (uint32_t)n, (double*)dq.p, (double*)dr.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(quot, dq.p, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(root, dr.p, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_buf(da);
+    free_buf(db);
+    free_buf(dq);
+    free_buf(dr);
+    if (e != hipSuccess) return ctx->fail_hip("pt_selftest_arith", e);
+    return PT_OK;
+}
+
+int pt_selftest_rng(PtContext* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!out || n == 0 || n > 65536) return ctx->fail(PT_ERR_BAD_ARG, "pt_selftest_rng: bad argument");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    hipError_t e = ensure_buf(d, (size_t)n * 8);
+    if (e == hipSuccess) {
+        launch_selftest_rng(ctx->stream, seed, pixel, sample, stream, n, (double*)d.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_buf(d);
+    if (e != hipSuccess) return ctx->fail_hip("pt_selftest_rng", e);
+    return PT_OK;
+}
+
+int pt_selftest_texture(PtContext* ctx, uint32_t tex, const double* points, size_t n, double* rgb_out) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_selftest_texture: no scene uploaded");
+    if (!points || !rgb_out || n == 0 || n > ((size_t)1 << 24) || tex >= ctx->sc.n_textures)
+        return ctx->fail(PT_ERR_BAD_ARG, "pt_selftest_texture: bad argument");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf dp, dc;
+    hipError_t e = ensure_buf(dp, n * 24);
+    if (e == hipSuccess) e = ensure_buf(dc, n * 24);
+    if (e == hipSuccess) e = hipMemcpyAsync(dp.p, points, n * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        launch_selftest_texture(ctx->stream, ctx->sc, tex, (const double*)dp.p, (uint32_t)n, (double*)dc.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgb_out, dc.p, n * 24, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_buf(dp);
+    free_buf(dc);
+    if (e != hipSuccess) return ctx->fail_hip("pt_selftest_texture", e);
+    return PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// resolve.hip -- the per-pixel tail of renderer::render (renderer.rs:27-33) and small utility kernels.
+#include "pt_launch.h"
+
+// color_sampling += sample (renderer.rs:27): the pass's per-path radiance slots are summed per pixel in
+// sample-slot order (a fixed order: the result is bit-reproducible), then added to the running sum.
+__global__ __launch_bounds__(PT_BLOCK) void fold_kernel(const float4* plane, uint32_t npix, uint32_t sample_slots, float* accum) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x; pix < npix; pix += stride) {
+        float r = 0.f, g = 0.f, b = 0.f;
+        for (uint32_t s = 0; s < sample_slots; ++s) {
+            float4 v = plane[(size_t)s * npix + pix];
+            r += v.x;
+            g += v.y;
+            b += v.z;
+        }
+        float* dst = accum + (size_t)pix * 3;
+        dst[0] += r;
+        dst[1] += g;
+        dst[2] += b;
+    }
+}
+
+void launch_fold(hipStream_t s, const PassParams& p, const Wavefront& wf, uint32_t sample_slots, float* accum) {
+    uint32_t blocks = (p.npix + PT_BLOCK - 1) / PT_BLOCK;
+    if (blocks > 8192u) blocks = 8192u;
+    hipLaunchKernelGGL(fold_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, wf.plane, p.npix, sample_slots, accum);
+}
+
+__global__ void count_totals_kernel(const uint32_t* counts, unsigned long long* totals, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) totals[i] += counts[i];
+}
+void launch_count_totals(hipStream_t s, const Wavefront& wf, uint32_t n_counts) {
+    hipLaunchKernelGGL(count_totals_kernel, dim3((n_counts + 63) / 64), dim3(64), 0, s, wf.counts, wf.totals, n_counts);
+}
+
+// (sum / spp).sqrt() then `(c * 255.999) as u8` (renderer.rs:30-33, vec3.rs:278-290): Rust's float->int
+// cast saturates and maps NaN to 0.
+__global__ __launch_bounds__(PT_BLOCK) void resolve_kernel(const float* accum, uint32_t n_values, double spp, uint8_t* rgb) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride) {
+        double c = sqrt((double)accum[i] / spp);
+        double v = c * 255.999;
+        uint8_t q;
+        if (!(v == v)) q = 0;
+        else if (v <= 0.0) q = 0;
+        else if (v >= 255.0) q = 255;
+        else q = (uint8_t)v;
+        rgb[i] = q;
+    }
+}
+void launch_resolve(hipStream_t s, const float* accum, uint32_t n_values, uint32_t total_spp, uint8_t* rgb) {
+    uint32_t blocks = (n_values + PT_BLOCK - 1) / PT_BLOCK;
+    if (blocks > 8192u) blocks = 8192u;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, accum, n_values, (double)total_spp, rgb);
+}
+
+// ---- device-side checks of the arithmetic the parity contract leans on
+__global__ void selftest_arith_kernel(const double* a, const double* b, uint32_t n, double* quot, double* root) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        quot[i] = a[i] / b[i];
+        root[i] = sqrt(fabs(a[i]));
+    }
+}
+void launch_selftest_arith(hipStream_t s, const double* a, const double* b, uint32_t n, double* quot, double* root) {
+    hipLaunchKernelGGL(selftest_arith_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, quot, root);
+}
+__global__ void selftest_rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        SampleRng rng;
+        rng.init(seed, pixel, sample, stream);
+        for (uint32_t i = 0; i < n; ++i) out[i] = rng.f64();
+    }
+}
+void launch_selftest_rng(hipStream_t s, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out) {
+    hipLaunchKernelGGL(selftest_rng_kernel, dim3(1), dim3(64), 0, s, seed, pixel, sample, stream, n, out);
+}
+__global__ void selftest_texture_kernel(DevScene sc, uint32_t tex, const double* points, uint32_t n, double* rgb) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        V3 c = texture_value(sc, tex, v3(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]));
+        rgb[3 * (size_t)i] = c.x;
+        rgb[3 * (size_t)i + 1] = c.y;
+        rgb[3 * (size_t)i + 2] = c.z;
+    }
+}
+void launch_selftest_texture(hipStream_t s, const DevScene& sc, uint32_t tex, const double* points, uint32_t n, double* rgb) {
+    hipLaunchKernelGGL(selftest_texture_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sc, tex, points, n, rgb);
+}

@@ -1,0 +1,103 @@
+// trace.hip -- closest-hit query per live ray: BvhNode::hit (bvh.rs:107-121) over the flattened tree.
+//
+// Persistent blocks: each block stages the scene prefix (the top BVH levels, or the whole scene when it is
+// small) in LDS once, then strides over the live rays.  A lane's pending right children sit on a stack in
+// LDS laid out [level][thread], so a wave's push/pop touches 64 consecutive banks.
+// Reads 48 B/ray (three coalesced 16-B streams), writes 12 B/ray (t, primitive).
+#include "pt_launch.h"
+
+__device__ __forceinline__ void stage_scene(const DevScene& sc, unsigned char* smem) {
+    // nodes are 64 B, primitives 80 B: copy as 16-B pieces
+    const uint4* src_n = reinterpret_cast<const uint4*>(sc.nodes);
+    uint4* dst_n = reinterpret_cast<uint4*>(smem);
+    const uint32_t pieces_n = sc.lds_nodes * 4u;
+    for (uint32_t k = threadIdx.x; k < pieces_n; k += blockDim.x) dst_n[k] = src_n[k];
+    const uint4* src_p = reinterpret_cast<const uint4*>(sc.prims);
+    uint4* dst_p = reinterpret_cast<uint4*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode));
+    const uint32_t pieces_p = sc.lds_prims * 5u;
+    for (uint32_t k = threadIdx.x; k < pieces_p; k += blockDim.x) dst_p[k] = src_p[k];
+    __syncthreads();
+}
+
+template <bool ALL_LDS>
+__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, RayStream rays, const uint32_t* count_ptr,
+                                                         double* hit_t, int32_t* hit_prim) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    stage_scene(sc, smem);
+    const DevNode* lds_nodes = reinterpret_cast<const DevNode*>(smem);
+    const DevPrim* lds_prims = reinterpret_cast<const DevPrim*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode));
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode) +
+                                                  (size_t)sc.lds_prims * sizeof(DevPrim)) + threadIdx.x;
+    const uint32_t n = *count_ptr;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        double2 a = rays.a[i], b = rays.b[i], c = rays.c[i];
+        double t;
+        int32_t prim;
+        // ray.rs:25: t_min = 0.001, t_max = +inf
+        traverse<ALL_LDS>(sc, lds_nodes, lds_prims, stack, v3(a.x, a.y, b.x), v3(b.y, c.x, c.y), 0.001,
+                          __builtin_huge_val(), t, prim);
+        hit_t[i] = t;
+        hit_prim[i] = prim;
+    }
+}
+
+void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, uint32_t bounce) {
+    const RayStream& in = wf.rays[bounce & 1u];
+    if (g.all_lds)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, wf.counts + bounce,
+                           wf.hit_t, wf.hit_prim);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, wf.counts + bounce,
+                           wf.hit_t, wf.hit_prim);
+}
+
+// Parity entry: the same traversal on caller-supplied rays (AoS, as the C ABI takes them), full record out.
+template <bool ALL_LDS>
+__global__ __launch_bounds__(PT_BLOCK) void trace_batch_kernel(DevScene sc, const double* origins, const double* dirs,
+                                                               uint32_t n, double t_min, double t_max, PtHitOut* out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    stage_scene(sc, smem);
+    const DevNode* lds_nodes = reinterpret_cast<const DevNode*>(smem);
+    const DevPrim* lds_prims = reinterpret_cast<const DevPrim*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode));
+    uint32_t* stack = reinterpret_cast<uint32_t*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode) +
+                                                  (size_t)sc.lds_prims * sizeof(DevPrim)) + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        V3 o = v3(origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]);
+        V3 d = v3(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]);
+        double t;
+        int32_t prim;
+        traverse<ALL_LDS>(sc, lds_nodes, lds_prims, stack, o, d, t_min, t_max, t, prim);
+        PtHitOut h;
+        h.prim = prim;
+        if (prim >= 0) {
+            const DevPrim* pr = sc.prims + prim;
+            V3 p = o + t * d; // ray.rs:16-18
+            V3 n_out = outward_normal(sc, pr, (uint32_t)prim, p);
+            bool front = dot(d, n_out) < 0.0; // geometry.rs:29
+            V3 nn = front ? n_out : neg(n_out);
+            h.front_face = front ? 1u : 0u;
+            h.t = t;
+            h.normal[0] = nn.x; h.normal[1] = nn.y; h.normal[2] = nn.z;
+        } else {
+            h.front_face = 0u;
+            h.t = 0.0;
+            h.normal[0] = h.normal[1] = h.normal[2] = 0.0;
+        }
+        out[i] = h;
+    }
+}
+
+void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const double* origins, const double* dirs,
+                        uint32_t n, double t_min, double t_max, PtHitOut* out) {
+    uint32_t blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
+    if (blocks > g.grid) blocks = g.grid;
+    if (blocks == 0) blocks = 1;
+    if (g.all_lds)
+        hipLaunchKernelGGL(trace_batch_kernel<true>, dim3(blocks), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, origins, dirs, n,
+                           t_min, t_max, out);
+    else
+        hipLaunchKernelGGL(trace_batch_kernel<false>, dim3(blocks), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, origins, dirs, n,
+                           t_min, t_max, out);
+}
