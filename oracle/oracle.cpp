@@ -775,6 +775,7 @@ std::shared_ptr<ObjModel> build_obj_model(const OrcMeshDesc* meshes, int n_meshe
             mapped.push_back(lambertian_color(Color((double)m.kd[0], (double)m.kd[1], (double)m.kd[2])));
     }
     std::vector<HittablePtr> world;
+    std::shared_ptr<Material> default_material = lambertian_color(Color(0.2, 0.7, 0.2)); // :82-84 (one instance, same values)
     for (int mi = 0; mi < n_meshes; ++mi) { // :53-100
         const OrcMeshDesc& mesh = meshes[mi];
         for (uint64_t tri = 0; tri < mesh.n_indices / 3; ++tri) {
@@ -783,7 +784,7 @@ std::shared_ptr<ObjModel> build_obj_model(const OrcMeshDesc* meshes, int n_meshe
             Vec3 v1((double)mesh.positions[i1 * 3], (double)mesh.positions[i1 * 3 + 1], (double)mesh.positions[i1 * 3 + 2]);
             Vec3 v2((double)mesh.positions[i2 * 3], (double)mesh.positions[i2 * 3 + 1], (double)mesh.positions[i2 * 3 + 2]);
             std::shared_ptr<Material> material =
-                mesh.material_id >= 0 ? mapped[mesh.material_id] : lambertian_color(Color(0.2, 0.7, 0.2));
+                mesh.material_id >= 0 ? mapped[mesh.material_id] : default_material;
             if (mesh.n_normals == 0) {
                 world.push_back(std::make_shared<Triangle>(v0, v1, v2, material));
             } else { // :90-95 -- indexed by vertex 0's POSITION index, verbatim, not normalised

@@ -109,17 +109,20 @@ __device__ __forceinline__ V3 random_in_unitdisk_xy(SampleRng& rng) { // vec3.rs
 }
 
 // ------------------------------------------------------------------ device scene tables
-struct DevNode { // = PtNode (bvh.rs:57-62); nodes are stored breadth-first so the top levels form a prefix
+struct DevNode { // bvh.rs:57-62, padded to 64 B (four 16-B pieces); stored breadth-first so the top levels form a prefix
     double bmin[3];
     double bmax[3];
     uint32_t left, right;
+    uint32_t pad[2];
 };
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
 struct DevPrim { // 80 B: what the hit test reads
     // sphere: c[3], r | rect: k, a_lo, a_hi, b_lo, b_hi | triangle: point1[3], point2-point1 [3], point3-point1 [3]
     double d[9];
     uint32_t type;
     uint32_t material;
 };
+static_assert(sizeof(DevPrim) == 80, "DevPrim must be 80 bytes");
 struct DevScene {
     const DevNode* nodes;
     const DevPrim* prims;

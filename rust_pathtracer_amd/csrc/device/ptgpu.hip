@@ -367,6 +367,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     for (uint32_t i = 0; i < s->n_nodes; ++i) {
         const PtNode& src = s->nodes[order[i]];
         DevNode& dst = nodes[i];
+        std::memset(&dst, 0, sizeof(dst));
         for (int k = 0; k < 3; ++k) {
             dst.bmin[k] = src.bmin[k];
             dst.bmax[k] = src.bmax[k];

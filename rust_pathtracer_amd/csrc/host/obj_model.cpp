@@ -186,6 +186,8 @@ std::shared_ptr<ObjModel> ObjModel::new_from_arrays(const ObjFile& file, BuildRn
     }
     // obj_model.rs:52-100
     std::vector<HittablePtr> world;
+    // obj_model.rs:82-84 makes a fresh Lambertian(0.2, 0.7, 0.2) per triangle; one shared instance renders the same
+    std::shared_ptr<Material> default_material = LambertianMaterial::new_from_color(Color(0.2, 0.7, 0.2));
     for (const ObjMesh& mesh : file.models) {
         const size_t n_pos = mesh.positions.size() / 3;
         for (size_t tri = 0; tri < mesh.indices.size() / 3; ++tri) {
@@ -199,7 +201,7 @@ std::shared_ptr<ObjModel> ObjModel::new_from_arrays(const ObjFile& file, BuildRn
                 if ((size_t)mesh.material_id >= materials_mapped.size()) throw std::runtime_error("mesh material out of range");
                 material = materials_mapped[mesh.material_id];
             } else {
-                material = LambertianMaterial::new_from_color(Color(0.2, 0.7, 0.2)); // obj_model.rs:82-84
+                material = default_material;
             }
             if (mesh.normals.empty()) {
                 world.push_back(Triangle::new_without_normal(v0, v1, v2, material));

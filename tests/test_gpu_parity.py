@@ -1,0 +1,311 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through size-independent
+properties.  Bar (BASELINE.json north_star): hit primitive index bit-exact, t and normals within 1e-5 relative
+(they come out bit-exact: same IEEE operations in the same order); accumulated images within f32 rounding of the
+oracle's f64 sums (tolerance written at each assert); hit-query counts exactly equal."""
+import os
+
+import numpy as np
+import pytest
+
+import scenes_util as su
+from rust_pathtracer_amd import api
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.npz")
+BG = {"SphereField": (1, 1, 1), "TwoSpheres": (1, 1, 1), "LightTest": (0, 0, 0), "CornellBox": (0, 0, 0), "TriangleTest": (0, 0, 0)}
+T_REL = 1e-5  # the contract's bound on t and normals
+
+
+def assert_hits_equal(hits, prim, t, normal, front, exact=True):
+    assert np.array_equal(hits["prim"], prim), f"{(hits['prim'] != prim).sum()} of {len(prim)} hit primitives differ"
+    h = prim >= 0
+    assert np.array_equal(hits["front_face"][h].astype(np.uint8), front[h])
+    # equal_nan: a ray lying in a rectangle's plane makes the reference itself return t = NaN (geometry.rs:211-221:
+    # NaN fails every rejection test); oracle and GPU reproduce that identically
+    assert np.allclose(hits["t"][h], t[h], rtol=T_REL, atol=0, equal_nan=True)
+    assert np.allclose(hits["normal"][h], normal[h], rtol=T_REL, atol=1e-12, equal_nan=True)
+    if exact:  # stronger than the contract: same bits
+        assert np.array_equal(hits["t"][h], t[h], equal_nan=True) and np.array_equal(hits["normal"][h], normal[h], equal_nan=True)
+
+
+# ---------------------------------------------------------------- arithmetic the contract leans on
+def test_device_division_and_sqrt_are_correctly_rounded(gpu_ctx):
+    rng = np.random.default_rng(0)
+    n = 1 << 18
+    a = rng.standard_normal(n) * 10.0 ** rng.integers(-150, 150, n)
+    b = rng.standard_normal(n) * 10.0 ** rng.integers(-150, 150, n)
+    a[:8] = [0.0, -0.0, 1.0, np.inf, 5e-324, 1e-310, 3.0, -7.0]
+    b[:8] = [1.0, 2.0, 0.0, 3.0, 3.0, 7.0, 1e-310, np.inf]
+    q, r = gpu_ctx.selftest_arith(a, b)
+    with np.errstate(all="ignore"):
+        assert np.array_equal(q, a / b, equal_nan=True)
+        assert np.array_equal(r, np.sqrt(np.abs(a)), equal_nan=True)
+
+
+def test_device_rng_stream_matches_oracle(gpu_ctx, oracle):
+    for seed, pixel, sample, stream in [(1, 0, 0, 0), (0x1234567890ABCDEF, 17, 3, 2), (2 ** 64 - 1, 2 ** 32 - 1, 1023, 51)]:
+        assert np.array_equal(gpu_ctx.selftest_rng(seed, pixel, sample, stream, 33), oracle.sample_draws(seed, pixel, sample, stream, 33))
+    g = np.load(GOLDEN)
+    assert np.array_equal(gpu_ctx.selftest_rng(0x1234567890ABCDEF, 17, 3, 2, 16), g["draws"])
+
+
+# ---------------------------------------------------------------- trace: fixed ray batches
+@pytest.mark.parametrize("name", su.NAMED)
+def test_trace_matches_golden(gpu_ctx, pt, name):
+    g = np.load(GOLDEN)
+    s = pt.Scene(name).set_seeds(1, 1, 1).build()
+    gpu_ctx.upload(s)
+    hits = gpu_ctx.trace_batch(g[f"{name}_o"], g[f"{name}_d"])
+    assert_hits_equal(hits, g[f"{name}_prim"], g[f"{name}_t"], g[f"{name}_normal"], g[f"{name}_front"])
+
+
+@pytest.mark.parametrize("name", su.NAMED)
+def test_trace_matches_oracle_named(gpu_ctx, oracle, name):
+    s, o = su.named_pair(name, 2, 3, 4)
+    gpu_ctx.upload(s)
+    cam = s.camera(0.6).as_array()
+    ro, rd = su.camera_rays(cam, 64, 36, 60000, 21)
+    p2, d2 = su.bounce_rays(o, ro, rd, 22)
+    p3, d3 = su.bounce_rays(o, p2, d2, 23)
+    ro, rd = np.concatenate([ro, p2, p3]), np.concatenate([rd, d2, d3])
+    prim, t, normal, front = o.trace(ro, rd)
+    assert (prim >= 0).mean() > 0.3
+    assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_trace_matches_oracle_random_worlds(gpu_ctx, oracle, seed):
+    s, o = su.random_world(seed, n_objects=48, with_mesh=(seed % 2 == 0))
+    gpu_ctx.upload(s)
+    ro, rd = su.random_rays(seed + 50, 80000)
+    p2, d2 = su.bounce_rays(o, ro, rd, seed + 60)
+    ro, rd = np.concatenate([ro, p2]), np.concatenate([rd, d2])
+    prim, t, normal, front = o.trace(ro, rd)
+    assert (prim >= 0).mean() > 0.1 and len(np.unique(prim)) > 20
+    assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
+    # other [t_min, t_max] windows (the interval ends are inclusive, geometry.rs:143-146,212,544)
+    for t_min, t_max in [(0.0, 5.0), (2.0, 9.0), (1e-9, 0.5)]:
+        prim, t, normal, front = o.trace(ro[:20000], rd[:20000], t_min, t_max)
+        assert_hits_equal(gpu_ctx.trace_batch(ro[:20000], rd[:20000], t_min, t_max), prim, t, normal, front)
+
+
+def test_trace_edge_cases(gpu_ctx, oracle):
+    s, o = su.random_world(7, n_objects=30)
+    gpu_ctx.upload(s)
+    assert len(gpu_ctx.trace_batch(np.zeros((0, 3)), np.zeros((0, 3)))) == 0  # empty batch
+    # axis-parallel rays (a zero direction component: inv_d = +-inf in the slab test, bvh.rs:22) and ragged sizes
+    rng = np.random.default_rng(3)
+    for n in (1, 63, 64, 65, 257, 1000):
+        ro = rng.uniform(-12, 12, (n, 3))
+        rd = np.zeros((n, 3))
+        rd[np.arange(n), rng.integers(0, 3, n)] = rng.choice([-1.0, 1.0], n)
+        rd[::3, 1] = -0.0
+        prim, t, normal, front = o.trace(ro, rd)
+        assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
+
+
+# ---------------------------------------------------------------- textures (libm differs: tolerance, not bits)
+def test_texture_values_match_oracle(gpu_ctx, pt, oracle):
+    s = pt.Scene("TwoSpheres").set_seeds(1, 1, 9).build()
+    gpu_ctx.upload(s)
+    d = s.desc
+    types = [d.textures[i].type for i in range(d.n_textures)]
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform(-12, 12, (20000, 3)), rng.uniform(-1000, 1000, (20000, 3))])
+    got = gpu_ctx.selftest_texture(types.index(api.TEX_CHECKER), pts)
+    want = oracle.texture_value(0, 0.0, 0, pts)
+    # a checker flips colour where the sine product crosses 0: allow the few points within an ulp of a boundary
+    assert (np.abs(got - want).max(axis=1) > 0).mean() < 1e-4
+    got = gpu_ctx.selftest_texture(types.index(api.TEX_PERLIN), pts)
+    want = oracle.texture_value(1, 4.0, 9, pts)
+    assert np.abs(got - want).max() < 1e-9  # sin of an argument up to ~4e3 evaluated by two libms
+
+
+# ---------------------------------------------------------------- whole render loop against the oracle
+def render_pair(ctx, oracle_scene, cam, w, h, bg, s0, n, depth, seed):
+    ctx.accum_reset(w, h)
+    stats = ctx.render_accumulate(cam, w, h, bg, s0, n, depth, seed)
+    got = ctx.accum_download().astype(np.float64)
+    want, rays = oracle_scene.render_accumulate(cam.as_array(), w, h, bg, s0, n, depth, seed)
+    return stats, got, want, rays
+
+
+def assert_images_close(got, want, spp):
+    # f32 throughput/radiance products and sums vs the oracle's f64: relative 2e-6 per operation, a few dozen operations
+    tol = 1e-4 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol, f"max |gpu - oracle| = {np.abs(got - want).max()} > {tol}"
+
+
+@pytest.mark.parametrize("name", su.NAMED)
+def test_render_matches_oracle_named(gpu_ctx, oracle, name):
+    w, h, spp, depth, seed = 64, 36, 5, 50, 11
+    s, o = su.named_pair(name, 1, 1, 1, image=(w, h, spp, depth, BG[name]))
+    gpu_ctx.upload(s)
+    stats, got, want, rays = render_pair(gpu_ctx, o, s.camera(0.3), w, h, BG[name], 3, spp, depth, seed)
+    assert stats.rays == rays and stats.paths == w * h * spp  # hit queries: exactly the oracle's count
+    assert sum(stats.rays_per_bounce) == rays and stats.rays_per_bounce[0] == w * h * spp
+    assert_images_close(got, want, spp)
+    img = gpu_ctx.resolve(spp)
+    ref = oracle.resolve(want, spp)
+    assert np.abs(img.astype(int) - ref.astype(int)).max() <= 1 and (img != ref).mean() < 0.01
+    assert np.array_equal(img, oracle.resolve(got, spp))  # the resolve kernel itself is exact on the same sums
+
+
+def test_golden_render_matches(gpu_ctx, pt):
+    g = np.load(GOLDEN)
+    w, h, spp, depth, seed = [int(x) for x in g["params"]]
+    for name in su.NAMED:
+        s = pt.Scene(name).set_seeds(1, 1, 1).set_image(w, h, spp, depth, BG[name]).build()
+        gpu_ctx.upload(s)
+        gpu_ctx.accum_reset(w, h)
+        cam = s.camera(0.25)
+        assert np.array_equal(cam.as_array(), g[f"{name}_cam"])
+        stats = gpu_ctx.render_accumulate(cam, w, h, BG[name], 0, spp, depth, seed)
+        assert stats.rays == int(g[f"{name}_rays"][0])
+        assert_images_close(gpu_ctx.accum_download().astype(np.float64), g[f"{name}_accum"], spp)
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_render_matches_oracle_random_world(gpu_ctx, oracle, pt, seed):
+    w, h, spp, depth = 48, 40, 4, 20  # not multiples of 8 x 8 tiles in one dimension only: exercises both raygen orders below
+    s, o = su.random_world(seed, n_objects=40, with_mesh=(seed == 0))
+    gpu_ctx.upload(s)
+    cam = pt.camera_new((25, 8, 25), (0, 0, 0), (0, 1, 0), 40.0, w / h, 0.4, 30.0)  # wide aperture: lens sampling matters
+    stats, got, want, rays = render_pair(gpu_ctx, o, cam, w, h, (0.6, 0.7, 0.9), 0, spp, depth, 5)
+    assert stats.rays == rays
+    assert_images_close(got, want, spp)
+    w2, h2 = 45, 37  # ragged: the linear raygen order
+    cam2 = pt.camera_new((25, 8, 25), (0, 0, 0), (0, 1, 0), 40.0, w2 / h2, 0.4, 30.0)
+    stats, got, want, rays = render_pair(gpu_ctx, o, cam2, w2, h2, (0.6, 0.7, 0.9), 0, spp, depth, 5)
+    assert stats.rays == rays
+    assert_images_close(got, want, spp)
+
+
+def test_render_model_scene_matches_oracle(gpu_ctx, oracle):
+    w, h, spp, depth = 40, 40, 3, 20
+    s, o = su.model_pair(48, 25, 1.3, (0.0, 1.5, 0.0), image=(w, h, spp, depth, (1, 1, 1)))
+    gpu_ctx.upload(s)
+    stats, got, want, rays = render_pair(gpu_ctx, o, s.camera(0.0), w, h, (1, 1, 1), 0, spp, depth, 2)
+    assert stats.rays == rays
+    assert_images_close(got, want, spp)
+
+
+def test_render_is_deterministic_and_pass_invariant(gpu_ctx, pt):
+    w, h, depth, seed = 64, 40, 30, 4
+    s = pt.Scene("CornellBox").set_image(w, h, 12, depth, (0, 0, 0)).build()
+    gpu_ctx.upload(s)
+    cam = s.camera(0.0)
+
+    def run(ranges, paths_per_pass):
+        gpu_ctx.set_option("paths_per_pass", paths_per_pass)
+        gpu_ctx.accum_reset(w, h)
+        rays = 0
+        passes = 0
+        for b, n in ranges:
+            st = gpu_ctx.render_accumulate(cam, w, h, (0, 0, 0), b, n, depth, seed)
+            rays += st.rays
+            passes += st.passes
+        return gpu_ctx.accum_download(), rays, passes
+
+    try:
+        a1, r1, p1 = run([(0, 12)], 1 << 25)
+        a2, r2, p2 = run([(0, 12)], 1 << 25)
+        assert p1 == 1 and np.array_equal(a1, a2) and r1 == r2  # no atomics on the image: bit-reproducible
+        a3, r3, p3 = run([(0, 12)], w * h * 5)  # 12 samples as passes of 5 + 5 + 2 sample slots
+        assert p3 == 3 and r3 == r1 and np.allclose(a3, a1, rtol=1e-5, atol=1e-5)
+        a4, r4, _ = run([(0, 5), (5, 7)], 1 << 25)  # disjoint sample ranges add up (what the multi-GPU reduce relies on)
+        assert r4 == r1 and np.allclose(a4, a1, rtol=1e-5, atol=1e-5)
+        a5, r5, _ = run([(5, 7), (0, 5)], 1 << 25)
+        assert r5 == r1 and np.allclose(a5, a1, rtol=1e-5, atol=1e-5)
+    finally:
+        gpu_ctx.set_option("paths_per_pass", 1 << 25)
+
+
+def test_depth_zero_and_background(gpu_ctx, pt):
+    s = pt.Scene("TwoSpheres").set_image(16, 8, 2, 3, (1, 1, 1)).build()
+    gpu_ctx.upload(s)
+    cam = s.camera(0.0)
+    gpu_ctx.accum_reset(16, 8)
+    st = gpu_ctx.render_accumulate(cam, 16, 8, (1, 1, 1), 0, 2, 0, 1)  # ray.rs:21-23: depth 0 is black, no query
+    assert st.rays == 0 and not gpu_ctx.accum_download().any()
+    st = gpu_ctx.render_accumulate(cam, 16, 8, (1, 1, 1), 0, 1, 1, 1)  # depth 1: hits are black, misses are background
+    a = gpu_ctx.accum_download()
+    assert st.rays == 128 and set(np.unique(a)) <= {0.0, 1.0}
+    away = pt.camera_new((13, 2, 3), (26, 4, 6), (0, 1, 0), 20.0, 2.0, 0.0, 10.0)
+    gpu_ctx.accum_reset(16, 8)
+    st = gpu_ctx.render_accumulate(away, 16, 8, (0.25, 0.5, 0.75), 0, 3, 9, 1)
+    assert st.rays == 384 and np.array_equal(gpu_ctx.accum_download().reshape(-1, 3), np.tile([0.75, 1.5, 2.25], (128, 1)).astype(np.float32))
+
+
+def test_drop_in_render_matches_oracle_image(pt, oracle):
+    # renderer::render(world, camera, w, h, background, spp, depth) -> Vec<u8> through the host layer, nothing else
+    w, h, spp, depth = 80, 45, 16, 50
+    s, o = su.named_pair("LightTest", 1, 1, 1, image=(w, h, spp, depth, (0, 0, 0)))
+    img, stats = s.render(0, 0.0, seed=6)
+    want, rays = o.render_accumulate(s.camera(0.0).as_array(), w, h, (0, 0, 0), 0, spp, depth, 6)
+    ref = oracle.resolve(want, spp)
+    assert img.shape == (h, w, 3) and stats.rays == rays
+    assert np.abs(img.astype(int) - ref.astype(int)).max() <= 1
+    rmse = np.sqrt(np.mean((img.astype(float) - ref.astype(float)) ** 2)) / 255.0
+    assert rmse < 0.01  # the contract's image bound; here the same samples are drawn, so it is ~0
+
+
+def test_external_accumulation_buffer(gpu_ctx, pt):
+    torch = pytest.importorskip("torch")
+    w, h, spp, depth = 32, 24, 3, 10
+    s = pt.Scene("TriangleTest").set_image(w, h, spp, depth, (0, 0, 0)).build()
+    gpu_ctx.upload(s)
+    cam = s.camera(0.0)
+    gpu_ctx.accum_reset(w, h)
+    gpu_ctx.render_accumulate(cam, w, h, (0, 0, 0), 0, spp, depth, 1)
+    own = gpu_ctx.accum_download()
+    buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.accum_bind(buf.data_ptr())
+    try:
+        assert gpu_ctx.accum_device_ptr() == buf.data_ptr()
+        gpu_ctx.render_accumulate(cam, w, h, (0, 0, 0), 0, spp, depth, 1)
+        assert np.array_equal(buf.cpu().numpy(), own)
+        assert np.array_equal(gpu_ctx.resolve(spp), gpu_ctx.resolve(spp))
+    finally:
+        gpu_ctx.accum_bind(None)
+
+
+# ---------------------------------------------------------------- error behaviour on the device library
+def test_device_library_errors(pt, gpu_ctx):
+    ctx = pt.Context(0)
+    try:
+        with pytest.raises(pt.PtError, match="no scene"):
+            ctx.trace_batch(np.zeros((1, 3)), np.ones((1, 3)))
+        s = pt.Scene("CornellBox").build()
+        ctx.upload(s)
+        with pytest.raises(pt.PtError, match="before pt_accum_reset"):
+            ctx.render_accumulate(s.camera(0.0), 8, 8, (0, 0, 0), 0, 1, 2, 1)
+        ctx.accum_reset(8, 8)
+        with pytest.raises(pt.PtError, match="size differs"):
+            ctx.render_accumulate(s.camera(0.0), 16, 8, (0, 0, 0), 0, 1, 2, 1)
+        with pytest.raises(pt.PtError):
+            ctx.accum_reset(1, 8)  # (width - 1) divides, renderer.rs:23
+        # a table that breaks the contract is refused, not rendered
+        d = s.desc
+        bad = api.PtSceneDesc.from_buffer_copy(bytes(d))
+        bad.n_prims = d.n_prims - 1
+        with pytest.raises(pt.PtError):
+            ctx.upload(bad)
+        import ctypes as C
+
+        nodes = (api.PtNode * d.n_nodes)()
+        C.memmove(nodes, d.nodes, C.sizeof(nodes))
+        nodes[0].left, nodes[0].right = nodes[0].right, nodes[0].left  # primitives no longer in depth-first order
+        bad = api.PtSceneDesc.from_buffer_copy(bytes(d))
+        bad.nodes = C.cast(nodes, C.POINTER(api.PtNode))
+        with pytest.raises(pt.PtError, match="depth-first"):
+            ctx.upload(bad)
+        with pytest.raises(pt.PtError, match="unknown option"):
+            ctx.set_option("nope", 1)
+    finally:
+        ctx.close()
+    with pytest.raises(pt.PtError):
+        pt.Context(9999)
