@@ -66,7 +66,7 @@ def cpu_baseline(args, target_seconds):
     t0 = time.perf_counter()
     _, rays1 = sc.render_accumulate(cam, w, h, bg, 0, 1, args.depth, args.seed, threads)
     dt1 = time.perf_counter() - t0
-    spp = int(max(1, min(256, target_seconds / max(dt1, 1e-3))))
+    spp = int(max(1, min(4096, target_seconds / max(dt1, 1e-3))))
     t0 = time.perf_counter()
     _, rays = sc.render_accumulate(cam, w, h, bg, 0, spp, args.depth, args.seed, threads)
     dt = time.perf_counter() - t0
@@ -96,6 +96,7 @@ def main():
 
     import rust_pathtracer_amd as pt
     from rust_pathtracer_amd import sample_range_for_rank
+    from rust_pathtracer_amd.distributed import render_static_sharded
 
     dist = None
     if world > 1:
@@ -128,9 +129,14 @@ def main():
             torch.cuda.synchronize()
         else:
             ctx.accum_reset(w, h)
-        st = ctx.render_accumulate(cam, w, h, bg, s_begin, s_count, depth, args.seed) if s_count > 0 else pt.PtStats()
+        box = [pt.PtStats()]
+
+        def accumulate(begin, count):
+            box[0] = ctx.render_accumulate(cam, w, h, bg, begin, count, depth, args.seed)
+
+        render_static_sharded(accumulate, accum, spp, rank, world, dist)  # this rank's samples, then ONE reduce to rank 0
+        st = box[0]
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
             torch.cuda.synchronize()
         img = ctx.resolve(spp) if rank == 0 else None
         return st, img
