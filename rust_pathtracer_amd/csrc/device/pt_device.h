@@ -123,6 +123,17 @@ struct DevPrim { // 80 B: what the hit test reads
     uint32_t material;
 };
 static_assert(sizeof(DevPrim) == 80, "DevPrim must be 80 bytes");
+// One step of the wave-uniform walk used for small scenes: the tree in depth-first pre-order, boxes and
+// primitives inline.  kind 0 = node (d[0..5] = box, aux = index of the item after this subtree);
+// kind 1 + PT_PRIM_* = primitive (d = DevPrim::d, aux = primitive index).
+struct WalkItem {
+    uint32_t kind;
+    uint32_t aux;
+    double d[9];
+};
+static_assert(sizeof(WalkItem) == 80, "WalkItem must be 80 bytes");
+#define PT_WALK_MAX_ITEMS 192
+
 struct DevScene {
     const DevNode* nodes;
     const DevPrim* prims;
@@ -135,6 +146,8 @@ struct DevScene {
     uint32_t lds_nodes; // nodes [0, lds_nodes) are staged in LDS by the trace kernel
     uint32_t lds_prims; // primitives [0, lds_prims) likewise (all of them for small scenes)
     uint32_t stack_depth;
+    const WalkItem* walk; // non-null when the scene is small enough for the wave-uniform walk
+    uint32_t n_walk;
 };
 
 // ------------------------------------------------------------------ hit tests (t only; the record is rebuilt in shade)
@@ -277,6 +290,127 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const DevNode* lds_
                 if (sp == 0) break;
                 cur = stack[(--sp) * stride];
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the same walk, wave-uniform (small scenes)
+// All 64 lanes step through the pre-order item list together: the item index is a scalar, the item's box or
+// primitive parameters arrive by scalar loads and feed the VALU as SGPR operands, and the primitive-type
+// dispatch is a scalar branch -- no divergent control flow at all.  A lane that failed a node's box test
+// (bvh.rs:108-110) sits out until the walk leaves that subtree (`skip_until`); when no lane is left inside a
+// subtree the whole wave jumps over it.  Per lane this performs exactly the sequence of box and primitive
+// tests, with the same running t_max, as the stack walk above and as the reference recursion.
+// Straight-line (predicated) forms of the tests for the lockstep walk: every comparison of the reference is kept
+// as written (so NaNs fall the same way), only the early returns are folded into one boolean.
+__device__ __forceinline__ bool walk_aabb(const double* b, V3 o, V3 inv, double t_min, double t_max) { // bvh.rs:18-35
+    double t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
+    double lo = (inv.x < 0.0) ? t1 : t0, hi = (inv.x < 0.0) ? t0 : t1;
+    t_min = fmax(lo, t_min);
+    t_max = fmin(hi, t_max);
+    bool miss = t_max <= t_min;
+    t0 = (b[1] - o.y) * inv.y; t1 = (b[4] - o.y) * inv.y;
+    lo = (inv.y < 0.0) ? t1 : t0; hi = (inv.y < 0.0) ? t0 : t1;
+    t_min = fmax(lo, t_min);
+    t_max = fmin(hi, t_max);
+    miss |= t_max <= t_min;
+    t0 = (b[2] - o.z) * inv.z; t1 = (b[5] - o.z) * inv.z;
+    lo = (inv.z < 0.0) ? t1 : t0; hi = (inv.z < 0.0) ? t0 : t1;
+    t_min = fmax(lo, t_min);
+    t_max = fmin(hi, t_max);
+    miss |= t_max <= t_min;
+    return !miss;
+}
+__device__ __forceinline__ bool walk_rect(const double* g, double on, double dn, double oa, double da, double ob, double db,
+                                          double t_min, double t_max, double& t_out) { // geometry.rs:210-221 etc.
+    double t = (g[0] - on) / dn;
+    bool out = (t < t_min) | (t > t_max);
+    double a = oa + t * da;
+    double b = ob + t * db;
+    out |= (a < g[1]) | (a > g[2]) | (b < g[3]) | (b > g[4]);
+    t_out = t;
+    return !out;
+}
+__device__ __forceinline__ bool walk_sphere(const double* g, bool act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    V3 oc = o - v3(g[0], g[1], g[2]); // geometry.rs:132-148
+    double a = len_squared(d);
+    double half_b = dot(d, oc);
+    double c = len_squared(oc) - g[3] * g[3];
+    double dis = half_b * half_b - a * c;
+    bool cand = act & !(dis < 0.0);
+    bool hit = false;
+    if (__any(cand)) { // wave-uniform: skip the sqrt and divides when the whole wave misses
+        double sq = sqrt(dis);
+        double root = (-half_b - sq) / a;
+        bool out1 = (root < t_min) | (root > t_max);
+        hit = cand & !out1;
+        if (__any(cand & out1)) {
+            double root2 = (-half_b + sq) / a;
+            bool out2 = (root2 < t_min) | (root2 > t_max);
+            if (out1) root = root2;
+            hit = cand & !(out1 & out2);
+        }
+        t_out = root;
+    }
+    return hit;
+}
+__device__ __forceinline__ bool walk_triangle(const double* g, bool act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    V3 v0v1 = v3(g[3], g[4], g[5]); // geometry.rs:519-546
+    V3 v0v2 = v3(g[6], g[7], g[8]);
+    V3 pvec = cross(d, v0v2);
+    double det = dot(v0v1, pvec);
+    bool cand = act & !(det < 0.0001);
+    bool hit = false;
+    if (__any(cand)) {
+        double inv_det = 1.0 / det;
+        V3 tvec = o - v3(g[0], g[1], g[2]);
+        double u = dot(tvec, pvec) * inv_det;
+        bool ok = cand & ((u >= 0.0) & (u <= 1.0));
+        V3 qvec = cross(tvec, v0v1);
+        double v = dot(d, qvec) * inv_det;
+        ok &= !((v < 0.0) | (u + v > 1.0));
+        double t = dot(v0v2, qvec) * inv_det;
+        ok &= (t >= t_min) & (t <= t_max);
+        t_out = t;
+        hit = ok;
+    }
+    return hit;
+}
+
+__device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk, uint32_t n_walk, bool lane_live, V3 o, V3 d,
+                                              double t_min, double t_max, double& best_t, int32_t& best_prim) {
+    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    best_t = t_max;
+    best_prim = -1;
+    uint32_t skip_until = lane_live ? 0u : 0xFFFFFFFFu;
+    uint32_t i = 0;
+    while (i < n_walk) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const WalkItem it = walk[i]; // one 80-byte scalar fetch per step
+        const uint32_t kind = it.kind;
+        const uint32_t aux = it.aux;
+        const bool act = skip_until <= i;
+        if (kind == 0u) {
+            bool hit = act & walk_aabb(it.d, o, inv, t_min, best_t);
+            if (act & !hit) skip_until = aux;
+            i = __any(hit) ? i + 1u : aux;
+        } else {
+            if (__any(act)) {
+                double t = 0.0;
+                bool h;
+                switch (kind - 1u) { // wave-uniform: a scalar branch
+                    case PT_PRIM_SPHERE: h = walk_sphere(it.d, act, o, d, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_XY: h = act & walk_rect(it.d, o.z, d.z, o.x, d.x, o.y, d.y, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_XZ: h = act & walk_rect(it.d, o.y, d.y, o.x, d.x, o.z, d.z, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_YZ: h = act & walk_rect(it.d, o.x, d.x, o.y, d.y, o.z, d.z, t_min, best_t, t); break;
+                    default: h = walk_triangle(it.d, act, o, d, t_min, best_t, t); break;
+                }
+                if (h) {
+                    best_t = t;
+                    best_prim = (int32_t)aux;
+                }
+            }
+            i = i + 1u;
         }
     }
 }

@@ -25,7 +25,7 @@ struct PtContext {
     // scene
     bool has_scene = false;
     DevScene sc{};
-    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin;
+    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin, d_walk;
     LaunchGeom geom{};
 
     // accumulation
@@ -239,6 +239,7 @@ void pt_context_destroy(PtContext* ctx) {
     free_buf(ctx->d_mats);
     free_buf(ctx->d_texs);
     free_buf(ctx->d_perlin);
+    free_buf(ctx->d_walk);
     free_buf(ctx->d_accum_own);
     free_buf(ctx->d_rgb);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -376,9 +377,60 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
         dst.right = (src.right & PT_REF_LEAF) ? src.right : remap[src.right];
     }
 
+    // small scenes: the pre-order item list of the wave-uniform walk (pt_device.h traverse_walk)
+    std::vector<WalkItem> walk;
+    if ((uint64_t)s->n_nodes + s->n_prims <= PT_WALK_MAX_ITEMS) {
+        // iterative pre-order: (ref, parent item to patch when the subtree ends)
+        struct Frame { uint32_t ref; int stage; uint32_t item; };
+        std::vector<Frame> st;
+        st.push_back({s->root, 0, 0});
+        while (!st.empty()) {
+            Frame& fr = st.back();
+            if (fr.ref & PT_REF_LEAF) {
+                uint32_t first = fr.ref & PT_REF_INDEX_MASK, count = (fr.ref & PT_REF_GROUP6) ? 6u : 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    WalkItem it;
+                    std::memset(&it, 0, sizeof(it));
+                    it.kind = 1u + prims[first + k].type;
+                    it.aux = first + k;
+                    for (int q = 0; q < 9; ++q) it.d[q] = prims[first + k].d[q];
+                    walk.push_back(it);
+                }
+                st.pop_back();
+                continue;
+            }
+            const PtNode& nd = s->nodes[fr.ref];
+            if (fr.stage == 0) {
+                WalkItem it;
+                std::memset(&it, 0, sizeof(it));
+                it.kind = 0;
+                for (int q = 0; q < 3; ++q) {
+                    it.d[q] = nd.bmin[q];
+                    it.d[3 + q] = nd.bmax[q];
+                }
+                fr.item = (uint32_t)walk.size();
+                walk.push_back(it);
+                fr.stage = 1;
+                uint32_t child = nd.left;
+                st.push_back({child, 0, 0});
+            } else if (fr.stage == 1) {
+                fr.stage = 2;
+                uint32_t child = nd.right;
+                st.push_back({child, 0, 0});
+            } else {
+                walk[fr.item].aux = (uint32_t)walk.size();  // first item after this subtree
+                st.pop_back();
+            }
+        }
+    }
+
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_scene = false;
+    if (!walk.empty()) {
+        PT_HIP(ctx, ensure_buf(ctx->d_walk, walk.size() * sizeof(WalkItem)));
+        PT_HIP(ctx, hipMemcpy(ctx->d_walk.p, walk.data(), walk.size() * sizeof(WalkItem), hipMemcpyHostToDevice));
+    }
     PT_HIP(ctx, ensure_buf(ctx->d_nodes, nodes.size() * sizeof(DevNode)));
     PT_HIP(ctx, ensure_buf(ctx->d_prims, prims.size() * sizeof(DevPrim)));
     PT_HIP(ctx, ensure_buf(ctx->d_aux, aux.size() * sizeof(double)));
@@ -407,6 +459,8 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.n_textures = s->n_textures;
     sc.root = 0;  // the root is first in breadth-first order
     sc.stack_depth = tc.max_depth;
+    sc.walk = walk.empty() ? nullptr : (const WalkItem*)ctx->d_walk.p;
+    sc.n_walk = (uint32_t)walk.size();
 
     // LDS plan for the trace kernel: [staged nodes][staged primitives][per-lane stack]
     const size_t stack_bytes = (size_t)sc.stack_depth * PT_BLOCK * sizeof(uint32_t);

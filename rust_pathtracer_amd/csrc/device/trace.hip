@@ -42,8 +42,39 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, RayStream 
     }
 }
 
+// Small scenes: the wave-uniform walk (pt_device.h traverse_walk).  No LDS, no per-lane stack.
+__global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __restrict__ walk, uint32_t n_walk, RayStream rays,
+                                                              const uint32_t* __restrict__ count_ptr, double* __restrict__ hit_t,
+                                                              int32_t* __restrict__ hit_prim) {
+    const uint32_t n = *count_ptr;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // whole waves iterate together: the trip count is rounded up per wave and idle lanes are masked inside
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        const bool live = i < n;
+        double2 a = make_double2(0, 0), b = make_double2(0, 1), c = make_double2(0, 0);
+        if (live) {
+            a = rays.a[i];
+            b = rays.b[i];
+            c = rays.c[i];
+        }
+        double t;
+        int32_t prim;
+        traverse_walk(walk, n_walk, live, v3(a.x, a.y, b.x), v3(b.y, c.x, c.y), 0.001, __builtin_huge_val(), t, prim);
+        if (live) {
+            hit_t[i] = t;
+            hit_prim[i] = prim;
+        }
+    }
+}
+
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, uint32_t bounce) {
     const RayStream& in = wf.rays[bounce & 1u];
+    if (sc.walk) {
+        hipLaunchKernelGGL(trace_walk_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.n_walk, in, wf.counts + bounce,
+                           wf.hit_t, wf.hit_prim);
+        return;
+    }
     if (g.all_lds)
         hipLaunchKernelGGL(trace_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, wf.counts + bounce,
                            wf.hit_t, wf.hit_prim);
@@ -89,11 +120,54 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_kernel(DevScene sc, cons
     }
 }
 
+__device__ __forceinline__ void write_hit_record(const DevScene& sc, V3 o, V3 d, double t, int32_t prim, PtHitOut* out) {
+    PtHitOut h;
+    h.prim = prim;
+    if (prim >= 0) {
+        const DevPrim* pr = sc.prims + prim;
+        V3 p = o + t * d; // ray.rs:16-18
+        V3 n_out = outward_normal(sc, pr, (uint32_t)prim, p);
+        bool front = dot(d, n_out) < 0.0; // geometry.rs:29
+        V3 nn = front ? n_out : neg(n_out);
+        h.front_face = front ? 1u : 0u;
+        h.t = t;
+        h.normal[0] = nn.x; h.normal[1] = nn.y; h.normal[2] = nn.z;
+    } else {
+        h.front_face = 0u;
+        h.t = 0.0;
+        h.normal[0] = h.normal[1] = h.normal[2] = 0.0;
+    }
+    *out = h;
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void trace_batch_walk_kernel(DevScene sc, const double* __restrict__ origins,
+                                                                    const double* __restrict__ dirs, uint32_t n, double t_min,
+                                                                    double t_max, PtHitOut* __restrict__ out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        const bool live = i < n;
+        V3 o = v3(0, 0, 0), d = v3(1, 0, 0);
+        if (live) {
+            o = v3(origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]);
+            d = v3(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]);
+        }
+        double t;
+        int32_t prim;
+        traverse_walk(sc.walk, sc.n_walk, live, o, d, t_min, t_max, t, prim);
+        if (live) write_hit_record(sc, o, d, t, prim, out + i);
+    }
+}
+
 void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const double* origins, const double* dirs,
                         uint32_t n, double t_min, double t_max, PtHitOut* out) {
     uint32_t blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
     if (blocks > g.grid) blocks = g.grid;
     if (blocks == 0) blocks = 1;
+    if (sc.walk) {
+        hipLaunchKernelGGL(trace_batch_walk_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, sc, origins, dirs, n, t_min, t_max, out);
+        return;
+    }
     if (g.all_lds)
         hipLaunchKernelGGL(trace_batch_kernel<true>, dim3(blocks), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, origins, dirs, n,
                            t_min, t_max, out);
