@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBDIR = os.path.join(_HERE, "lib")
+_LIBDIR = os.environ.get("PT_LIBDIR") or os.path.join(_HERE, "lib")  # PT_LIBDIR: A/B builds of the same libraries
 
 
 class PtError(RuntimeError):

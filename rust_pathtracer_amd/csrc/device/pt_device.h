@@ -48,8 +48,11 @@ __device__ __forceinline__ bool near_zero(V3 a) {                               
 // thread_rng (renderer.rs:23-24, vec3.rs:27-29,35-37,59-60, material.rs:132).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t out[4]) {
+#ifndef PT_PHILOX_ROUNDS
+#define PT_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PT_PHILOX_ROUNDS; ++r) {
         uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         uint32_t n0 = hi1 ^ c1 ^ k0;
@@ -93,6 +96,9 @@ __device__ __forceinline__ V3 random_in_unitsphere(SampleRng& rng) { // vec3.rs:
         double y = rng.range(-1.0, 1.0);
         double z = rng.range(-1.0, 1.0);
         p = v3(x, y, z);
+#ifdef PT_ABLATE_NO_REJECT
+        break;
+#endif
         if (len_squared(p) < 1.0) break;
     }
     return p;
@@ -133,6 +139,22 @@ struct WalkItem {
 };
 static_assert(sizeof(WalkItem) == 80, "WalkItem must be 80 bytes");
 #define PT_WALK_MAX_ITEMS 192
+// Everything shade needs about the primitive it hit, in ONE 80-byte record (one dependent fetch instead of the
+// chain primitive -> material -> texture): the geometry the normal comes from, the material, and the colour
+// when the material's texture is a solid one.
+struct ShadePrim {
+    double g[4];        // sphere: center, radius | rectangle, triangle: outward / stored normal, 0
+    double param;       // metal fuzz / dielectric index of refraction
+    uint32_t prim_type; // PT_PRIM_*
+    uint32_t mat_type;  // PT_MAT_*
+    uint32_t texture;   // texture index (procedural lookups)
+    uint32_t tex_solid; // 1: `color` below is the texture's value everywhere
+    float color[3];     // (f32 of the f64 colour: what the f32 radiometry multiplies by)
+    float pad0;
+    double pad1;
+};
+static_assert(sizeof(ShadePrim) == 80, "ShadePrim must be 80 bytes");
+#define PT_SHADE_LDS_MAX_PRIMS 256
 
 struct DevScene {
     const DevNode* nodes;
@@ -148,6 +170,8 @@ struct DevScene {
     uint32_t stack_depth;
     const WalkItem* walk; // non-null when the scene is small enough for the wave-uniform walk
     uint32_t n_walk;
+    uint32_t has_procedural; // any checker / marble texture
+    const ShadePrim* shade_prims;
 };
 
 // ------------------------------------------------------------------ hit tests (t only; the record is rebuilt in shade)
@@ -425,21 +449,19 @@ __device__ __forceinline__ V3 outward_normal(const DevScene& sc, const DevPrim* 
 
 // ------------------------------------------------------------------ textures (texture.rs)
 // noise 0.8.2 Perlin stand-in: improved 3-D Perlin over a 256-entry permutation.
+// The 16 gradient cases of the noise crate's table -- 0|12: x+y, 1|13: -x+y, 2: x-y, 3: -x-y, 4: x+z, 5: -x+z,
+// 6: x-z, 7: -x-z, 8: y+z, 9|14: -y+z, 10: y-z, 11|15: -y-z -- without a 16-way branch: fold 12..15 onto
+// 0, 1, 9, 11, then case h is (+-a) + (+-b) with (a, b) = (x,y), (x,z), (y,z) for h>>2 = 0, 1, 2.
+// (-a) + (-b) has the same bits as -a - b, and a + (-b) the same as a - b.
 __device__ __forceinline__ double perlin_grad(int h, double x, double y, double z) {
-    switch (h & 15) {
-        case 0: case 12: return x + y;
-        case 1: case 13: return -x + y;
-        case 2: return x - y;
-        case 3: return -x - y;
-        case 4: return x + z;
-        case 5: return -x + z;
-        case 6: return x - z;
-        case 7: return -x - z;
-        case 8: return y + z;
-        case 9: case 14: return -y + z;
-        case 10: return y - z;
-        default: return -y - z;
-    }
+    const unsigned long long fold = 0xB910BA9876543210ull;
+    const unsigned hh = (unsigned)(fold >> ((h & 15) * 4)) & 15u;
+    const unsigned group = hh >> 2;
+    double a = (group == 2u) ? y : x;
+    double b = (group == 0u) ? y : z;
+    a = (hh & 1u) ? -a : a;
+    b = (hh & 2u) ? -b : b;
+    return a + b;
 }
 __device__ __forceinline__ int perlin_hash(const uint8_t* perm, long x, long y, long z) {
     int a = perm[x & 0xff];
@@ -475,9 +497,10 @@ __device__ inline double perlin_get(const uint8_t* perm, double px, double py, d
     return r;
 }
 // Texture::value (texture.rs:19-23, :36-45, :75-80); u,v are unused by every texture the reference ships.
-__device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 p) {
-    for (uint32_t guard = 0; guard <= sc.n_textures; ++guard) {
-        const PtTexture* t = sc.textures + tex;
+__device__ __noinline__ V3 texture_value_procedural(const PtTexture* textures, uint32_t n_textures, const uint8_t* perlin,
+                                                    uint32_t tex, V3 p) {
+    for (uint32_t guard = 0; guard <= n_textures; ++guard) {
+        const PtTexture* t = textures + tex;
         if (t->type == PT_TEX_CHECKER) {
             double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
             tex = (sines < 0.0) ? t->odd : t->even;
@@ -485,7 +508,7 @@ __device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 p) {
         }
         if (t->type == PT_TEX_SOLID) return v3(t->color[0], t->color[1], t->color[2]);
         // marble: texture.rs:60-80, 7 octaves
-        const uint8_t* perm = sc.perlin + (size_t)t->perlin_table * 256;
+        const uint8_t* perm = perlin + (size_t)t->perlin_table * 256;
         double accumulator = 0.0, weight = 1.0;
         double qx = p.x, qy = p.y, qz = p.z;
         for (int i = 0; i < 7; ++i) {
@@ -498,6 +521,16 @@ __device__ inline V3 texture_value(const DevScene& sc, uint32_t tex, V3 p) {
         return v3(1.0 * c, 1.0 * c, 1.0 * c);
     }
     return v3(0.0, 0.0, 0.0);
+}
+// Solid colours (every material of the Cornell box) are answered inline; checker and marble go through ONE
+// out-of-line body so their sin() and noise code is not replicated at every call site.
+// PROCEDURAL = false is for scenes whose textures are all solid: the kernel then carries neither the call nor the
+// callee's register budget.
+template <bool PROCEDURAL>
+__device__ __forceinline__ V3 texture_value(const DevScene& sc, uint32_t tex, V3 p) {
+    const PtTexture* t = sc.textures + tex;
+    if (!PROCEDURAL || t->type == PT_TEX_SOLID) return v3(t->color[0], t->color[1], t->color[2]);
+    return texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, tex, p);
 }
 
 // ------------------------------------------------------------------ materials (material.rs)
@@ -513,9 +546,9 @@ __device__ __forceinline__ double reflectance(double cosine, double refraction_i
 
 // Material::scatter for the hit (point p, unit-or-not normal n already flipped to oppose the ray).
 // Returns false when the path ends (no scatter).  attenuation is evaluated by the caller via texture_value.
-__device__ __forceinline__ bool scatter(const PtMaterial& m, V3 ray_d, V3 n, bool front_face, SampleRng& rng, V3& out_d,
-                                        bool& textured) {
-    switch (m.type) {
+__device__ __forceinline__ bool scatter(uint32_t mat_type, double mat_param, V3 ray_d, V3 n, bool front_face, SampleRng& rng,
+                                        V3& out_d, bool& textured) {
+    switch (mat_type) {
         case PT_MAT_LAMBERTIAN: { // material.rs:41-55
             V3 dir = n + unit_vector(random_in_unitsphere(rng));
             if (near_zero(dir)) dir = n;
@@ -526,14 +559,14 @@ __device__ __forceinline__ bool scatter(const PtMaterial& m, V3 ray_d, V3 n, boo
         case PT_MAT_METAL: { // material.rs:77-93
             V3 reflected = reflect(unit_vector(ray_d), n);
             if (dot(reflected, n) > 0.0) {
-                out_d = reflected + m.param * random_in_unitsphere(rng);
+                out_d = reflected + mat_param * random_in_unitsphere(rng);
                 textured = true;
                 return true;
             }
             return false;
         }
         case PT_MAT_DIELECTRIC: { // material.rs:117-143
-            double refraction_ratio = front_face ? 1.0 / m.param : m.param;
+            double refraction_ratio = front_face ? 1.0 / mat_param : mat_param;
             V3 unit_direction = unit_vector(ray_d);
             double cos_theta = fmin(dot(neg(unit_direction), n), 1.0);
             double sin_theta = sqrt(1.0 - cos_theta * cos_theta);

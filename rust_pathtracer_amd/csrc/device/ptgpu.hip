@@ -25,7 +25,7 @@ struct PtContext {
     // scene
     bool has_scene = false;
     DevScene sc{};
-    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin, d_walk;
+    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin, d_walk, d_shade;
     LaunchGeom geom{};
 
     // accumulation
@@ -240,6 +240,7 @@ void pt_context_destroy(PtContext* ctx) {
     free_buf(ctx->d_texs);
     free_buf(ctx->d_perlin);
     free_buf(ctx->d_walk);
+    free_buf(ctx->d_shade);
     free_buf(ctx->d_accum_own);
     free_buf(ctx->d_rgb);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -377,6 +378,28 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
         dst.right = (src.right & PT_REF_LEAF) ? src.right : remap[src.right];
     }
 
+    // per-primitive shading records (pt_device.h ShadePrim)
+    std::vector<ShadePrim> shade_prims(s->n_prims);
+    for (uint32_t i = 0; i < s->n_prims; ++i) {
+        const PtPrim& p = s->prims[i];
+        const PtMaterial& m = s->materials[p.material];
+        ShadePrim& q = shade_prims[i];
+        std::memset(&q, 0, sizeof(q));
+        if (p.type == PT_PRIM_SPHERE) {
+            for (int k = 0; k < 4; ++k) q.g[k] = p.d[k];
+        } else {
+            for (int k = 0; k < 3; ++k) q.g[k] = aux[(size_t)i * 3 + k];
+        }
+        q.param = m.param;
+        q.prim_type = p.type;
+        q.mat_type = m.type;
+        q.texture = m.texture;
+        if (m.type != PT_MAT_DIELECTRIC && s->textures[m.texture].type == PT_TEX_SOLID) {
+            q.tex_solid = 1;
+            for (int k = 0; k < 3; ++k) q.color[k] = (float)s->textures[m.texture].color[k];
+        }
+    }
+
     // small scenes: the pre-order item list of the wave-uniform walk (pt_device.h traverse_walk)
     std::vector<WalkItem> walk;
     if ((uint64_t)s->n_nodes + s->n_prims <= PT_WALK_MAX_ITEMS) {
@@ -427,6 +450,8 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     PT_HIP(ctx, hipSetDevice(ctx->device));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_scene = false;
+    PT_HIP(ctx, ensure_buf(ctx->d_shade, shade_prims.size() * sizeof(ShadePrim)));
+    PT_HIP(ctx, hipMemcpy(ctx->d_shade.p, shade_prims.data(), shade_prims.size() * sizeof(ShadePrim), hipMemcpyHostToDevice));
     if (!walk.empty()) {
         PT_HIP(ctx, ensure_buf(ctx->d_walk, walk.size() * sizeof(WalkItem)));
         PT_HIP(ctx, hipMemcpy(ctx->d_walk.p, walk.data(), walk.size() * sizeof(WalkItem), hipMemcpyHostToDevice));
@@ -461,6 +486,10 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.stack_depth = tc.max_depth;
     sc.walk = walk.empty() ? nullptr : (const WalkItem*)ctx->d_walk.p;
     sc.n_walk = (uint32_t)walk.size();
+    sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
+    sc.has_procedural = 0;
+    for (uint32_t i = 0; i < s->n_textures; ++i)
+        if (s->textures[i].type != PT_TEX_SOLID) sc.has_procedural = 1;
 
     // LDS plan for the trace kernel: [staged nodes][staged primitives][per-lane stack]
     const size_t stack_bytes = (size_t)sc.stack_depth * PT_BLOCK * sizeof(uint32_t);

@@ -80,7 +80,7 @@ void launch_selftest_rng(hipStream_t s, uint64_t seed, uint32_t pixel, uint32_t 
 __global__ void selftest_texture_kernel(DevScene sc, uint32_t tex, const double* points, uint32_t n, double* rgb) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        V3 c = texture_value(sc, tex, v3(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]));
+        V3 c = texture_value<true>(sc, tex, v3(points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2]));
         rgb[3 * (size_t)i] = c.x;
         rgb[3 * (size_t)i + 1] = c.y;
         rgb[3 * (size_t)i + 2] = c.z;

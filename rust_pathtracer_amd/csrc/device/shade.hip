@@ -31,9 +31,19 @@ __device__ __forceinline__ void add_radiance(float4* plane, uint32_t path, float
     plane[path] = v;
 }
 
+// PROCEDURAL: the scene has checker / marble textures (else the kernel carries neither the call nor its registers).
+// TABLE_LDS: the ShadePrim table is small enough to be staged in LDS once per block.
+template <bool PROCEDURAL, bool TABLE_LDS>
 __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs a) {
     __shared__ uint32_t s_wave[PT_BLOCK / PT_WAVE];
     __shared__ uint32_t s_base;
+    __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
+    if (TABLE_LDS) {
+        const uint4* src = reinterpret_cast<const uint4*>(sc.shade_prims);
+        uint4* dst = reinterpret_cast<uint4*>(s_table);
+        for (uint32_t k = threadIdx.x; k < sc.n_prims * 5u; k += PT_BLOCK) dst[k] = src[k];
+        __syncthreads();
+    }
     const uint32_t n = a.counts[a.bounce];
     const bool last_bounce = (a.bounce + 1u >= a.max_bounces);
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);
@@ -44,44 +54,46 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0);
         uint4 st = make_uint4(0, 0, 0, 0);
         if (i < n) {
+            // all six stream loads are issued together: one memory latency, not a chain of them
             st = a.state_in[i];
             const int32_t prim = a.hit_prim[i];
+            const double2 ra = a.in.a[i], rb = a.in.b[i], rc = a.in.c[i];
+            const double t = a.hit_t[i];
             float tr = __uint_as_float(st.y), tg = __uint_as_float(st.z), tb = __uint_as_float(st.w);
             if (prim < 0) {
                 if (has_bg) add_radiance(a.plane, st.x, tr, tg, tb, a.bg[0], a.bg[1], a.bg[2]);
             } else {
-                double2 ra = a.in.a[i], rb = a.in.b[i], rc = a.in.c[i];
+                const ShadePrim sp = TABLE_LDS ? reinterpret_cast<const ShadePrim*>(s_table)[prim] : sc.shade_prims[prim];
                 V3 o = v3(ra.x, ra.y, rb.x), d = v3(rb.y, rc.x, rc.y);
-                const double t = a.hit_t[i];
-                const DevPrim* pr = sc.prims + prim;
-                const PtMaterial m = sc.materials[pr->material];
                 V3 p = o + t * d;                                        // ray.rs:16-18
-                V3 n_out = outward_normal(sc, pr, (uint32_t)prim, p);
+                V3 n_out = v3(sp.g[0], sp.g[1], sp.g[2]);                // geometry.rs:227 / :290 / :353 / :554
+                if (sp.prim_type == PT_PRIM_SPHERE) n_out = (p - n_out) / sp.g[3]; // geometry.rs:151
                 bool front = dot(d, n_out) < 0.0;                        // geometry.rs:29
                 V3 nn = front ? n_out : neg(n_out);                      // geometry.rs:33-37
-                if (m.type == PT_MAT_DIFFUSE_LIGHT) {                    // material.rs:158-166
-                    if (front) {
-                        V3 e = texture_value(sc, m.texture, p);
-                        add_radiance(a.plane, st.x, tr, tg, tb, (float)e.x, (float)e.y, (float)e.z);
-                    }
+                // ONE texture lookup per hit: the light's emission (material.rs:158-166) or the scatterer's albedo
+                bool emits = false, textured = false;
+                if (sp.mat_type == PT_MAT_DIFFUSE_LIGHT) {
+                    emits = front;
                 } else if (!last_bounce) {
                     uint32_t slot = st.x / a.npix;
                     uint32_t pixel = st.x - slot * a.npix;
                     SampleRng rng;
                     rng.init(a.seed, pixel, a.sample_base + slot, a.bounce + 1u);
-                    bool textured = false;
-                    alive = scatter(m, d, nn, front, rng, next_d, textured);
-                    if (alive) {
-                        next_o = p;
-                        if (textured) {
-                            V3 att = texture_value(sc, m.texture, p);
-                            tr *= (float)att.x;
-                            tg *= (float)att.y;
-                            tb *= (float)att.z;
-                            st.y = __float_as_uint(tr);
-                            st.z = __float_as_uint(tg);
-                            st.w = __float_as_uint(tb);
-                        }
+                    alive = scatter(sp.mat_type, sp.param, d, nn, front, rng, next_d, textured);
+                    next_o = p;
+                }
+                if (emits || (alive && textured)) {
+                    float cr = sp.color[0], cg = sp.color[1], cb = sp.color[2];
+                    if (PROCEDURAL && !sp.tex_solid) {
+                        V3 c = texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, sp.texture, p);
+                        cr = (float)c.x; cg = (float)c.y; cb = (float)c.z;
+                    }
+                    if (emits) {
+                        add_radiance(a.plane, st.x, tr, tg, tb, cr, cg, cb);
+                    } else {
+                        st.y = __float_as_uint(tr * cr);
+                        st.z = __float_as_uint(tg * cg);
+                        st.w = __float_as_uint(tb * cb);
                     }
                 }
             }
@@ -126,5 +138,12 @@ void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
     a.sample_base = p.sample_base;
     a.seed = p.seed;
     a.bg[0] = p.bg[0]; a.bg[1] = p.bg[1]; a.bg[2] = p.bg[2];
-    hipLaunchKernelGGL(shade_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+    const bool lds = sc.n_prims <= PT_SHADE_LDS_MAX_PRIMS;
+    if (sc.has_procedural) {
+        if (lds) hipLaunchKernelGGL((shade_kernel<true, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+        else hipLaunchKernelGGL((shade_kernel<true, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+    } else {
+        if (lds) hipLaunchKernelGGL((shade_kernel<false, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+        else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+    }
 }
