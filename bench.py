@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--paths-per-pass", type=int, default=0, help="0 = library default")
+    ap.add_argument("--repack-every", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--repack-first", type=int, default=-1)
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     return ap.parse_args()
@@ -114,6 +117,12 @@ def main():
     ctx = pt.Context(local_rank)
     if args.paths_per_pass:
         ctx.set_option("paths_per_pass", args.paths_per_pass)
+    if args.blocks_per_cu:
+        ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+    if args.repack_every >= 0:
+        ctx.set_option("repack_every", args.repack_every)
+    if args.repack_first >= 0:
+        ctx.set_option("repack_first", args.repack_first)
     ctx.upload(scene)
     ctx.accum_reset(w, h)
     accum = None
@@ -152,7 +161,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     rays = 0
-    ms_trace = ms_shade = ms_raygen = ms_fold = 0.0
+    ms_trace = ms_shade = ms_raygen = ms_fold = ms_repack = 0.0
     n_trace = n_shade = 0
     shade_in = shade_out = 0
     img = None
@@ -163,6 +172,7 @@ def main():
         ms_shade += st.ms_shade
         ms_raygen += st.ms_raygen
         ms_fold += st.ms_fold
+        ms_repack += st.ms_repack
         n_trace += st.launches_trace
         n_shade += st.launches_shade
         rpb = list(st.rays_per_bounce)
@@ -226,7 +236,8 @@ def main():
                 "pipeline_frac": round(mrays * 1e6 * BYTES_SEGMENT / world / (HBM_PEAK_GBS * 1e9), 5),
             },
             "kernel_ms_per_step": {"raygen": round(ms_raygen / args.steps, 3), "trace": round(ms_trace / args.steps, 3),
-                                   "shade": round(ms_shade / args.steps, 3), "fold": round(ms_fold / args.steps, 3)},
+                                   "shade": round(ms_shade / args.steps, 3), "fold": round(ms_fold / args.steps, 3),
+                                   "repack": round(ms_repack / args.steps, 3)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

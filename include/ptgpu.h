@@ -130,6 +130,7 @@ typedef struct PtStats {
     double ms_trace;
     double ms_shade;
     double ms_fold;
+    double ms_repack;
     uint64_t rays_per_bounce[64]; /* live rays entering bounce b (b >= 64 folded into the last slot) */
 } PtStats;
 
@@ -145,8 +146,11 @@ void pt_context_destroy(PtContext* ctx);
 /* Message of the last failing call on ctx (or of the last failing pt_context_create when ctx is NULL). */
 const char* pt_last_error(const PtContext* ctx);
 
-/* Options: "paths_per_pass" (upper bound on paths in flight; default 64 Mi),
- * "profile" (1 = time every kernel with HIP events and fill PtStats.ms_*; default 1). */
+/* Options: "paths_per_pass" (upper bound on paths in flight, 156 B each; default 128 Mi),
+ * "profile" (1 = time every kernel with HIP events and fill PtStats.ms_*; default 1),
+ * "repack_every" / "repack_first" (re-deal surviving rays over the waves every N bounces from bounce F on;
+ *   default 0 = never / 8),
+ * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 
 /* Replaces scene.get_world()'s result (scene.rs:38-42): validates and uploads the flattened world.

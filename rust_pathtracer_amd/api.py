@@ -116,6 +116,7 @@ class PtStats(C.Structure):
         ("ms_trace", C.c_double),
         ("ms_shade", C.c_double),
         ("ms_fold", C.c_double),
+        ("ms_repack", C.c_double),
         ("rays_per_bounce", C.c_uint64 * 64),
     ]
 

@@ -36,13 +36,16 @@ struct PtContext {
 
     // wavefront streams
     size_t wf_capacity = 0;
+    size_t wf_paths = 0;
     uint32_t counts_cap = 0;
     Wavefront wf{};
     std::vector<DevBuf> wf_bufs;
 
     // options
-    int64_t paths_per_pass = (int64_t)1 << 25;
+    int64_t paths_per_pass = (int64_t)1 << 27;
     int profile = 1;
+    int blocks_per_cu_override = 0;
+    int repack_every = 0, repack_first = 8;  // measured on Cornell 1080p: the copy costs more than the fuller waves save
     std::vector<hipEvent_t> events;
 
     int fail(int code, const std::string& msg) {
@@ -82,19 +85,31 @@ void free_wavefront(PtContext* ctx) {
     ctx->wf_bufs.clear();
     ctx->wf = Wavefront{};
     ctx->wf_capacity = 0;
+    ctx->wf_paths = 0;
     ctx->counts_cap = 0;
 }
 
-int ensure_wavefront(PtContext* ctx, size_t capacity, uint32_t n_counts) {
-    if (ctx->wf_capacity >= capacity && ctx->counts_cap >= n_counts) return PT_OK;
+// Streams for n_paths paths in flight over the context's persistent grid, and per-wave counts for n_bounces + 1 bounces.
+int ensure_wavefront(PtContext* ctx, size_t n_paths, uint32_t n_bounces) {
+    const uint32_t n_waves = ctx->geom.grid * (PT_BLOCK / PT_WAVE);
+    const size_t chunks = (n_paths + 63) / 64;
+    const size_t region = ((chunks + n_waves - 1) / n_waves) * 64;
+    const size_t capacity = region * n_waves;
+    const uint32_t n_counts = n_bounces + 1;
+    if (region > 0xFFFFFFFFull) return ctx->fail(PT_ERR_BAD_ARG, "too many paths per pass");
+    if (ctx->wf_capacity >= capacity && ctx->wf_paths >= n_paths && ctx->counts_cap >= n_counts && ctx->wf.n_waves == n_waves) {
+        ctx->wf.region = (uint32_t)region;
+        return PT_OK;
+    }
     free_wavefront(ctx);
     const size_t sizes[] = {
         capacity * sizeof(double2), capacity * sizeof(double2), capacity * sizeof(double2),  // rays[0]
         capacity * sizeof(double2), capacity * sizeof(double2), capacity * sizeof(double2),  // rays[1]
         capacity * sizeof(uint4),   capacity * sizeof(uint4),                               // state
         capacity * sizeof(double),  capacity * sizeof(int32_t),                             // hits
-        capacity * sizeof(float4),                                                          // plane
-        (size_t)n_counts * sizeof(uint32_t), (size_t)n_counts * sizeof(unsigned long long)  // counts, totals
+        n_paths * sizeof(float4),                                                           // plane (by path slot)
+        (size_t)n_counts * (n_waves + 1) * sizeof(uint32_t), (size_t)n_counts * sizeof(unsigned long long),  // counts, totals
+        (size_t)n_counts * (n_waves + 1) * sizeof(uint32_t)                                                  // repacked counts
     };
     const size_t nb = sizeof(sizes) / sizeof(sizes[0]);
     ctx->wf_bufs.resize(nb);
@@ -115,7 +130,11 @@ int ensure_wavefront(PtContext* ctx, size_t capacity, uint32_t n_counts) {
     w.plane = (float4*)ctx->wf_bufs[10].p;
     w.counts = (uint32_t*)ctx->wf_bufs[11].p;
     w.totals = (unsigned long long*)ctx->wf_bufs[12].p;
+    w.counts_repacked = (uint32_t*)ctx->wf_bufs[13].p;
+    w.n_waves = n_waves;
+    w.region = (uint32_t)region;
     ctx->wf_capacity = capacity;
+    ctx->wf_paths = n_paths;
     ctx->counts_cap = n_counts;
     return PT_OK;
 }
@@ -257,6 +276,15 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
         ctx->paths_per_pass = value;
     } else if (k == "profile") {
         ctx->profile = value ? 1 : 0;
+    } else if (k == "repack_every") {  // re-deal the surviving rays over the waves every N bounces (0 = never)
+        if (value < 0 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "repack_every out of range");
+        ctx->repack_every = (int)value;
+    } else if (k == "repack_first") {  // first bounce before which a repack runs
+        if (value < 1 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "repack_first out of range");
+        ctx->repack_first = (int)value;
+    } else if (k == "blocks_per_cu") {  // tuning knob: persistent-grid blocks (of 4 waves) per CU; takes effect at the next upload
+        if (value < 0 || value > 16) return ctx->fail(PT_ERR_BAD_ARG, "blocks_per_cu out of range [0, 16]");
+        ctx->blocks_per_cu_override = (int)value;
     } else {
         return ctx->fail(PT_ERR_BAD_ARG, "unknown option " + k);
     }
@@ -507,7 +535,11 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
         sc.lds_prims = 0;
     }
     g.trace_lds_bytes = (size_t)sc.lds_nodes * sizeof(DevNode) + (size_t)sc.lds_prims * sizeof(DevPrim) + stack_bytes;
-    g.grid = (uint32_t)ctx->cu_count * 8u;
+    // Waves per CU of the persistent grid: 32 (8 per SIMD) when every kernel of the pass fits 8 waves per SIMD (small
+    // scene, solid textures); otherwise 24, a whole number of rounds for kernels that fit 6, 3 or 2 (no ragged last round).
+    uint32_t blocks_per_cu = (sc.walk && !sc.has_procedural) ? 8u : 6u;
+    if (ctx->blocks_per_cu_override > 0) blocks_per_cu = (uint32_t)ctx->blocks_per_cu_override;
+    g.grid = (uint32_t)ctx->cu_count * blocks_per_cu;
     ctx->has_scene = true;
     return PT_OK;
 }
@@ -590,8 +622,8 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     slots64 = std::min<uint64_t>(slots64, sample_count);
     slots64 = std::min<uint64_t>(slots64, 0xFFFFFFFFull / npix);
     const uint32_t slots = (uint32_t)slots64;
-    const uint32_t n_counts = max_bounces + 2;
-    int rc = ensure_wavefront(ctx, (size_t)slots * npix, n_counts);
+    const uint32_t n_counts = max_bounces + 1;
+    int rc = ensure_wavefront(ctx, (size_t)slots * npix, max_bounces);
     if (rc != PT_OK) return rc;
 
     PassParams p{};
@@ -604,7 +636,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     p.tiled = (width % 8 == 0 && height % 8 == 0) ? 1 : 0;
 
     // event bookkeeping: ev[k] separates launch k-1 from launch k; kinds[k] = what ran between ev[k] and ev[k+1]
-    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_GAP = 4 };
+    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_GAP = 4, K_REPACK = 5 };
     std::vector<int> kinds;
     size_t ev_used = 0;
     auto mark = [&](int kind_after) -> hipError_t {
@@ -625,21 +657,33 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         const uint32_t cur = std::min(slots, sample_count - done);
         p.n_paths = cur * npix;
         p.sample_base = sample_begin + done;
-        PT_HIP(ctx, hipMemsetAsync(ctx->wf.counts, 0, (size_t)n_counts * sizeof(uint32_t), ctx->stream));
         PT_HIP(ctx, mark(K_RAYGEN));
         launch_raygen(ctx->stream, ctx->geom, *camera, p, ctx->wf);
+        int buf = 0;                                   // ping-pong buffer holding this bounce's rays
+        const uint32_t* counts_in = ctx->wf.counts;   // row of bounce 0, written by raygen
         for (uint32_t b = 0; b < max_bounces; ++b) {
+            BounceIO io{buf, buf ^ 1, counts_in, ctx->wf.counts + count_row(ctx->wf, b + 1)};
             PT_HIP(ctx, mark(K_TRACE));
-            launch_trace(ctx->stream, ctx->geom, ctx->sc, ctx->wf, b);
+            launch_trace(ctx->stream, ctx->geom, ctx->sc, ctx->wf, io);
             PT_HIP(ctx, mark(K_SHADE));
-            launch_shade(ctx->stream, ctx->geom, ctx->sc, p, ctx->wf, b);
+            launch_shade(ctx->stream, ctx->geom, ctx->sc, p, ctx->wf, io, b);
             ++launches_trace;
             ++launches_shade;
+            buf ^= 1;
+            counts_in = io.counts_out;
+            const uint32_t every = (uint32_t)ctx->repack_every;
+            if (every && b + 1 < max_bounces && b + 1 >= (uint32_t)ctx->repack_first && (b + 1 - ctx->repack_first) % every == 0) {
+                BounceIO rp{buf, buf ^ 1, counts_in, ctx->wf.counts_repacked + count_row(ctx->wf, b + 1)};
+                PT_HIP(ctx, mark(K_REPACK));
+                launch_repack(ctx->stream, ctx->geom, ctx->wf, rp);
+                buf ^= 1;
+                counts_in = rp.counts_out;
+            }
         }
         PT_HIP(ctx, mark(K_FOLD));
         launch_fold(ctx->stream, p, ctx->wf, cur, ctx->d_accum);
         PT_HIP(ctx, mark(K_GAP));
-        launch_count_totals(ctx->stream, ctx->wf, n_counts);
+        launch_count_totals(ctx->stream, ctx->wf, max_bounces);
         PT_HIP(ctx, hipGetLastError());
         ++passes;
     }
@@ -669,6 +713,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_TRACE: stats->ms_trace += ms; break;
                     case K_SHADE: stats->ms_shade += ms; break;
                     case K_FOLD: stats->ms_fold += ms; break;
+                    case K_REPACK: stats->ms_repack += ms; break;
                     default: break;
                 }
             }

@@ -26,12 +26,22 @@ void launch_fold(hipStream_t s, const PassParams& p, const Wavefront& wf, uint32
     hipLaunchKernelGGL(fold_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, wf.plane, p.npix, sample_slots, accum);
 }
 
-__global__ void count_totals_kernel(const uint32_t* counts, unsigned long long* totals, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) totals[i] += counts[i];
+// totals[b] += sum over waves of counts[b][w]: one block per bounce.
+__global__ __launch_bounds__(PT_BLOCK) void count_totals_kernel(const uint32_t* counts, unsigned long long* totals, uint32_t n_waves) {
+    __shared__ unsigned long long s_sum[PT_BLOCK];
+    const uint32_t* row = counts + (size_t)blockIdx.x * (n_waves + 1u);
+    unsigned long long acc = 0;
+    for (uint32_t w = threadIdx.x; w < n_waves; w += PT_BLOCK) acc += row[w];
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t half = PT_BLOCK / 2; half > 0; half >>= 1) {
+        if (threadIdx.x < half) s_sum[threadIdx.x] += s_sum[threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] += s_sum[0];
 }
-void launch_count_totals(hipStream_t s, const Wavefront& wf, uint32_t n_counts) {
-    hipLaunchKernelGGL(count_totals_kernel, dim3((n_counts + 63) / 64), dim3(64), 0, s, wf.counts, wf.totals, n_counts);
+void launch_count_totals(hipStream_t s, const Wavefront& wf, uint32_t n_bounces) {
+    hipLaunchKernelGGL(count_totals_kernel, dim3(n_bounces), dim3(PT_BLOCK), 0, s, wf.counts, wf.totals, wf.n_waves);
 }
 
 // (sum / spp).sqrt() then `(c * 255.999) as u8` (renderer.rs:30-33, vec3.rs:278-290): Rust's float->int

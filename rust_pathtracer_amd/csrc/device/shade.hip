@@ -5,7 +5,8 @@
 //   scatter         -> T *= attenuation, next ray = scattered                      (ray.rs:28-34)
 //   depth exhausted -> path ends with nothing more added                           (ray.rs:21-23)
 // The hit record (point, normal, front_face; geometry.rs:20-43) is rebuilt from (ray, t, primitive).
-// Survivors are written compacted: wave ballot + mbcnt prefix, one atomicAdd per 256-thread block.
+// Survivors are written compacted inside the wave's private region (pt_launch.h): wave ballot + mbcnt prefix,
+// no atomics and no barriers.
 // Reads 76 B/ray (ray 48, hit 12, state 16), writes 64 B per surviving ray (ray 48, state 16).
 #include "pt_launch.h"
 
@@ -16,7 +17,9 @@ struct ShadeArgs {
     const double* hit_t;
     const int32_t* hit_prim;
     float4* plane;
-    uint32_t* counts;
+    const uint32_t* counts_in; // this bounce's per-wave counts
+    uint32_t* counts_out;      // next bounce's
+    uint32_t n_waves;
     uint32_t bounce, max_bounces, npix, sample_base;
     uint64_t seed;
     float bg[3];
@@ -35,8 +38,6 @@ __device__ __forceinline__ void add_radiance(float4* plane, uint32_t path, float
 // TABLE_LDS: the ShadePrim table is small enough to be staged in LDS once per block.
 template <bool PROCEDURAL, bool TABLE_LDS>
 __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs a) {
-    __shared__ uint32_t s_wave[PT_BLOCK / PT_WAVE];
-    __shared__ uint32_t s_base;
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
     if (TABLE_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.shade_prims);
@@ -44,16 +45,21 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
         for (uint32_t k = threadIdx.x; k < sc.n_prims * 5u; k += PT_BLOCK) dst[k] = src[k];
         __syncthreads();
     }
-    const uint32_t n = a.counts[a.bounce];
+    const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(a.counts_in[wave]);
+    const uint32_t region = a.counts_in[a.n_waves];
+    const size_t region_base = (size_t)wave * region;
     const bool last_bounce = (a.bounce + 1u >= a.max_bounces);
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * PT_BLOCK; base < n; base += gridDim.x * PT_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
+    uint32_t out_n = 0; // survivors this wave has written so far (wave-uniform)
+    for (uint32_t first = 0; first < n; first += 64u) {
+        const uint32_t k = first + lane;
+        const size_t i = region_base + k;
         bool alive = false;
         V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0);
         uint4 st = make_uint4(0, 0, 0, 0);
-        if (i < n) {
+        if (k < n) {
             // all six stream loads are issued together: one memory latency, not a chain of them
             st = a.state_in[i];
             const int32_t prim = a.hit_prim[i];
@@ -98,40 +104,36 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
                 }
             }
         }
-        if (last_bounce) continue; // nothing survives the last bounce (uniform across the block)
-        // ---- stream compaction
+        if (last_bounce) continue; // nothing survives the last bounce
+        // ---- stream compaction inside the wave's own region: rank by ballot + mbcnt, append at the running offset
         const unsigned long long mask = __ballot(alive);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-            s_base = total ? atomicAdd(&a.counts[a.bounce + 1u], total) : 0u;
-        }
-        __syncthreads();
         if (alive) {
-            uint32_t off = s_base + prefix;
-            for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
+            const size_t off = region_base + out_n + prefix;
             a.out.a[off] = make_double2(next_o.x, next_o.y);
             a.out.b[off] = make_double2(next_o.z, next_d.x);
             a.out.c[off] = make_double2(next_d.y, next_d.z);
             a.state_out[off] = st;
         }
-        __syncthreads(); // s_wave / s_base are reused by the next iteration
+        out_n += (uint32_t)__popcll(mask);
     }
+    if (lane == 0) a.counts_out[wave] = out_n;
+    if (wave == 0 && lane == 0) a.counts_out[a.n_waves] = region; // survivors stay in the same layout
 }
 
 void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf,
-                  uint32_t bounce) {
+                  const BounceIO& io, uint32_t bounce) {
     ShadeArgs a;
-    a.in = wf.rays[bounce & 1u];
-    a.out = wf.rays[(bounce + 1u) & 1u];
-    a.state_in = wf.state[bounce & 1u];
-    a.state_out = wf.state[(bounce + 1u) & 1u];
+    a.in = wf.rays[io.in];
+    a.out = wf.rays[io.out];
+    a.state_in = wf.state[io.in];
+    a.state_out = wf.state[io.out];
     a.hit_t = wf.hit_t;
     a.hit_prim = wf.hit_prim;
     a.plane = wf.plane;
-    a.counts = wf.counts;
+    a.counts_in = io.counts_in;
+    a.counts_out = io.counts_out;
+    a.n_waves = wf.n_waves;
     a.bounce = bounce;
     a.max_bounces = p.max_bounces;
     a.npix = p.npix;
@@ -146,4 +148,56 @@ void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
         if (lds) hipLaunchKernelGGL((shade_kernel<false, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
         else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
     }
+}
+
+// ------------------------------------------------------------------ repack
+// As paths die the per-wave regions thin out unevenly and a wave's last 64-ray chunk runs half empty.  Every few
+// bounces the survivors are dealt out again: an exclusive prefix over the per-wave counts (every block scans the
+// n_waves counts itself -- 32 KB from L2, no inter-block hand-off), each wave copies its rays to the contiguous
+// position prefix + k, and the new layout is read off that contiguous stream: region' = max(64, ceil(total /
+// n_waves) rounded up to 64), wave w' owning [w' * region', ...).  Copies 64 B per live ray.
+__global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const uint4* __restrict__ st_in, RayStream out,
+                                                          uint4* __restrict__ st_out, const uint32_t* __restrict__ counts_in,
+                                                          uint32_t* __restrict__ counts_out, uint32_t n_waves) {
+    __shared__ uint32_t s_part[PT_BLOCK];
+    const uint32_t per = (n_waves + PT_BLOCK - 1) / PT_BLOCK;
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+        uint32_t w = threadIdx.x * per + k;
+        if (w < n_waves) acc += counts_in[w];
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    // prefix of this wave and the grand total (wave-uniform; PT_BLOCK partial sums, read by every lane)
+    uint32_t prefix = 0, total = 0;
+    const uint32_t my_part = wave / per;
+    for (uint32_t t = 0; t < PT_BLOCK; ++t) {
+        uint32_t v = s_part[t];
+        if (t < my_part) prefix += v;
+        total += v;
+    }
+    for (uint32_t w = my_part * per; w < wave; ++w) prefix += counts_in[w];
+    const uint32_t n = counts_in[wave];
+    const size_t src_base = (size_t)wave * counts_in[n_waves];
+    for (uint32_t k = lane; k < n; k += 64u) {
+        const size_t src = src_base + k, dst = (size_t)prefix + k;
+        out.a[dst] = in.a[src];
+        out.b[dst] = in.b[src];
+        out.c[dst] = in.c[src];
+        st_out[dst] = st_in[src];
+    }
+    uint32_t region = ((total + n_waves - 1) / n_waves + 63u) & ~63u;
+    if (region < 64u) region = 64u;
+    if (lane == 0) {
+        const unsigned long long start = (unsigned long long)wave * region;
+        counts_out[wave] = start >= total ? 0u : (total - start < region ? (uint32_t)(total - start) : region);
+    }
+    if (wave == 0 && lane == 0) counts_out[n_waves] = region;
+}
+
+void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io) {
+    hipLaunchKernelGGL(repack_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, wf.rays[io.in], wf.state[io.in], wf.rays[io.out],
+                       wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves);
 }

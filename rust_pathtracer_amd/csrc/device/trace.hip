@@ -1,7 +1,7 @@
 // trace.hip -- closest-hit query per live ray: BvhNode::hit (bvh.rs:107-121) over the flattened tree.
 //
-// Persistent blocks: each block stages the scene prefix (the top BVH levels, or the whole scene when it is
-// small) in LDS once, then strides over the live rays.  A lane's pending right children sit on a stack in
+// Persistent grid: wave w walks its own region of the ray stream (pt_launch.h).  Stack variant: each block stages
+// the scene prefix (the top BVH levels, or the whole scene when it is small) in LDS once.  A lane's pending right children sit on a stack in
 // LDS laid out [level][thread], so a wave's push/pop touches 64 consecutive banks.
 // Reads 48 B/ray (three coalesced 16-B streams), writes 12 B/ray (t, primitive).
 #include "pt_launch.h"
@@ -20,17 +20,19 @@ __device__ __forceinline__ void stage_scene(const DevScene& sc, unsigned char* s
 }
 
 template <bool ALL_LDS>
-__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, RayStream rays, const uint32_t* count_ptr,
-                                                         double* hit_t, int32_t* hit_prim) {
+__global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, RayStream rays, const uint32_t* __restrict__ counts,
+                                                         uint32_t n_waves, double* hit_t, int32_t* hit_prim) {
     extern __shared__ __align__(16) unsigned char smem[];
     stage_scene(sc, smem);
     const DevNode* lds_nodes = reinterpret_cast<const DevNode*>(smem);
     const DevPrim* lds_prims = reinterpret_cast<const DevPrim*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode));
     uint32_t* stack = reinterpret_cast<uint32_t*>(smem + (size_t)sc.lds_nodes * sizeof(DevNode) +
                                                   (size_t)sc.lds_prims * sizeof(DevPrim)) + threadIdx.x;
-    const uint32_t n = *count_ptr;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t n = counts[wave];
+    const size_t base = (size_t)wave * counts[n_waves];
+    for (uint32_t k = threadIdx.x & 63u; k < n; k += 64u) {
+        const size_t i = base + k;
         double2 a = rays.a[i], b = rays.b[i], c = rays.c[i];
         double t;
         int32_t prim;
@@ -44,14 +46,15 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, RayStream 
 
 // Small scenes: the wave-uniform walk (pt_device.h traverse_walk).  No LDS, no per-lane stack.
 __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __restrict__ walk, uint32_t n_walk, RayStream rays,
-                                                              const uint32_t* __restrict__ count_ptr, double* __restrict__ hit_t,
-                                                              int32_t* __restrict__ hit_prim) {
-    const uint32_t n = *count_ptr;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    // whole waves iterate together: the trip count is rounded up per wave and idle lanes are masked inside
-    for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
-        const uint32_t i = base + (threadIdx.x & 63u);
-        const bool live = i < n;
+                                                              const uint32_t* __restrict__ counts, uint32_t n_waves,
+                                                              double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
+    const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(counts[wave]);
+    const size_t base = (size_t)wave * counts[n_waves];
+    for (uint32_t first = 0; first < n; first += 64u) { // whole waves iterate together; idle lanes are masked inside
+        const uint32_t k = first + (threadIdx.x & 63u);
+        const bool live = k < n;
+        const size_t i = base + k;
         double2 a = make_double2(0, 0), b = make_double2(0, 1), c = make_double2(0, 0);
         if (live) {
             a = rays.a[i];
@@ -68,19 +71,19 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __
     }
 }
 
-void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, uint32_t bounce) {
-    const RayStream& in = wf.rays[bounce & 1u];
+void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io) {
+    const RayStream& in = wf.rays[io.in];
     if (sc.walk) {
-        hipLaunchKernelGGL(trace_walk_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.n_walk, in, wf.counts + bounce,
+        hipLaunchKernelGGL(trace_walk_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.n_walk, in, io.counts_in, wf.n_waves,
                            wf.hit_t, wf.hit_prim);
         return;
     }
     if (g.all_lds)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, wf.counts + bounce,
-                           wf.hit_t, wf.hit_prim);
+        hipLaunchKernelGGL(trace_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, io.counts_in,
+                           wf.n_waves, wf.hit_t, wf.hit_prim);
     else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, wf.counts + bounce,
-                           wf.hit_t, wf.hit_prim);
+        hipLaunchKernelGGL(trace_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, in, io.counts_in,
+                           wf.n_waves, wf.hit_t, wf.hit_prim);
 }
 
 // Parity entry: the same traversal on caller-supplied rays (AoS, as the C ABI takes them), full record out.
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_walk_kernel(DevScene sc,
 void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const double* origins, const double* dirs,
                         uint32_t n, double t_min, double t_max, PtHitOut* out) {
     uint32_t blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
-    if (blocks > g.grid) blocks = g.grid;
+    if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) blocks = 1;
     if (sc.walk) {
         hipLaunchKernelGGL(trace_batch_walk_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, sc, origins, dirs, n, t_min, t_max, out);
