@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--paths-per-pass", type=int, default=0, help="0 = library default")
     ap.add_argument("--repack-every", type=int, default=-1, help="-1 = library default")
     ap.add_argument("--repack-first", type=int, default=-1)
+    ap.add_argument("--lanes", type=int, default=0, help="0 = library default")
+    ap.add_argument("--opt", action="append", default=[], help="library option key=value (repeatable)")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="0 = library default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
@@ -119,6 +121,11 @@ def main():
         ctx.set_option("paths_per_pass", args.paths_per_pass)
     if args.blocks_per_cu:
         ctx.set_option("blocks_per_cu", args.blocks_per_cu)
+    if args.lanes:
+        ctx.set_option("lanes", args.lanes)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     if args.repack_every >= 0:
         ctx.set_option("repack_every", args.repack_every)
     if args.repack_first >= 0:

@@ -7,6 +7,8 @@
 
 #include "pt_launch.h"
 
+#define PT_MAX_LANES 4
+
 namespace {
 thread_local std::string g_last_error;
 
@@ -18,7 +20,8 @@ struct DevBuf {
 
 struct PtContext {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // lane 0's stream; also every non-render call
+    hipStream_t extra_streams[PT_MAX_LANES - 1] = {};  // the other lanes' streams
     std::string err;
     int cu_count = 256;
 
@@ -34,12 +37,20 @@ struct PtContext {
     float* d_accum = nullptr;
     DevBuf d_rgb;
 
-    // wavefront streams
-    size_t wf_capacity = 0;
-    size_t wf_paths = 0;
-    uint32_t counts_cap = 0;
-    Wavefront wf{};
-    std::vector<DevBuf> wf_bufs;
+    // wavefront streams: two independent lanes (own buffers, own HIP stream) so that one lane's VALU-bound trace
+    // overlaps the other lane's memory-bound shade
+    struct Lane {
+        hipStream_t stream = nullptr;
+        size_t capacity = 0;
+        size_t paths = 0;
+        uint32_t counts_cap = 0;
+        Wavefront wf{};
+        std::vector<DevBuf> bufs;
+    };
+    Lane lanes[PT_MAX_LANES];
+    int n_lanes = 2;
+    int lane_sync = 0;
+    int lane_full_grid = 1;
 
     // options
     int64_t paths_per_pass = (int64_t)1 << 27;
@@ -80,28 +91,32 @@ hipError_t ensure_buf(DevBuf& b, size_t bytes) {
     return e;
 }
 
+void free_lane(PtContext::Lane& ln) {
+    for (auto& b : ln.bufs) free_buf(b);
+    ln.bufs.clear();
+    ln.wf = Wavefront{};
+    ln.capacity = 0;
+    ln.paths = 0;
+    ln.counts_cap = 0;
+}
 void free_wavefront(PtContext* ctx) {
-    for (auto& b : ctx->wf_bufs) free_buf(b);
-    ctx->wf_bufs.clear();
-    ctx->wf = Wavefront{};
-    ctx->wf_capacity = 0;
-    ctx->wf_paths = 0;
-    ctx->counts_cap = 0;
+    for (auto& ln : ctx->lanes) free_lane(ln);
 }
 
-// Streams for n_paths paths in flight over the context's persistent grid, and per-wave counts for n_bounces + 1 bounces.
-int ensure_wavefront(PtContext* ctx, size_t n_paths, uint32_t n_bounces) {
-    const uint32_t n_waves = ctx->geom.grid * (PT_BLOCK / PT_WAVE);
+// Streams of one lane for n_paths paths in flight over a persistent grid of `grid` blocks, and per-wave counts for
+// n_bounces + 1 bounces.
+int ensure_lane(PtContext* ctx, PtContext::Lane& ln, uint32_t grid, size_t n_paths, uint32_t n_bounces) {
+    const uint32_t n_waves = grid * (PT_BLOCK / PT_WAVE);
     const size_t chunks = (n_paths + 63) / 64;
     const size_t region = ((chunks + n_waves - 1) / n_waves) * 64;
     const size_t capacity = region * n_waves;
     const uint32_t n_counts = n_bounces + 1;
     if (region > 0xFFFFFFFFull) return ctx->fail(PT_ERR_BAD_ARG, "too many paths per pass");
-    if (ctx->wf_capacity >= capacity && ctx->wf_paths >= n_paths && ctx->counts_cap >= n_counts && ctx->wf.n_waves == n_waves) {
-        ctx->wf.region = (uint32_t)region;
+    if (ln.capacity >= capacity && ln.paths >= n_paths && ln.counts_cap >= n_counts && ln.wf.n_waves == n_waves) {
+        ln.wf.region = (uint32_t)region;
         return PT_OK;
     }
-    free_wavefront(ctx);
+    free_lane(ln);
     const size_t sizes[] = {
         capacity * sizeof(double2), capacity * sizeof(double2), capacity * sizeof(double2),  // rays[0]
         capacity * sizeof(double2), capacity * sizeof(double2), capacity * sizeof(double2),  // rays[1]
@@ -112,30 +127,30 @@ int ensure_wavefront(PtContext* ctx, size_t n_paths, uint32_t n_bounces) {
         (size_t)n_counts * (n_waves + 1) * sizeof(uint32_t)                                                  // repacked counts
     };
     const size_t nb = sizeof(sizes) / sizeof(sizes[0]);
-    ctx->wf_bufs.resize(nb);
+    ln.bufs.resize(nb);
     for (size_t i = 0; i < nb; ++i) {
-        hipError_t e = ensure_buf(ctx->wf_bufs[i], sizes[i]);
+        hipError_t e = ensure_buf(ln.bufs[i], sizes[i]);
         if (e != hipSuccess) {
-            free_wavefront(ctx);
+            free_lane(ln);
             return ctx->fail_hip("hipMalloc(wavefront streams)", e);
         }
     }
-    Wavefront& w = ctx->wf;
-    w.rays[0] = RayStream{(double2*)ctx->wf_bufs[0].p, (double2*)ctx->wf_bufs[1].p, (double2*)ctx->wf_bufs[2].p};
-    w.rays[1] = RayStream{(double2*)ctx->wf_bufs[3].p, (double2*)ctx->wf_bufs[4].p, (double2*)ctx->wf_bufs[5].p};
-    w.state[0] = (uint4*)ctx->wf_bufs[6].p;
-    w.state[1] = (uint4*)ctx->wf_bufs[7].p;
-    w.hit_t = (double*)ctx->wf_bufs[8].p;
-    w.hit_prim = (int32_t*)ctx->wf_bufs[9].p;
-    w.plane = (float4*)ctx->wf_bufs[10].p;
-    w.counts = (uint32_t*)ctx->wf_bufs[11].p;
-    w.totals = (unsigned long long*)ctx->wf_bufs[12].p;
-    w.counts_repacked = (uint32_t*)ctx->wf_bufs[13].p;
+    Wavefront& w = ln.wf;
+    w.rays[0] = RayStream{(double2*)ln.bufs[0].p, (double2*)ln.bufs[1].p, (double2*)ln.bufs[2].p};
+    w.rays[1] = RayStream{(double2*)ln.bufs[3].p, (double2*)ln.bufs[4].p, (double2*)ln.bufs[5].p};
+    w.state[0] = (uint4*)ln.bufs[6].p;
+    w.state[1] = (uint4*)ln.bufs[7].p;
+    w.hit_t = (double*)ln.bufs[8].p;
+    w.hit_prim = (int32_t*)ln.bufs[9].p;
+    w.plane = (float4*)ln.bufs[10].p;
+    w.counts = (uint32_t*)ln.bufs[11].p;
+    w.totals = (unsigned long long*)ln.bufs[12].p;
+    w.counts_repacked = (uint32_t*)ln.bufs[13].p;
     w.n_waves = n_waves;
     w.region = (uint32_t)region;
-    ctx->wf_capacity = capacity;
-    ctx->wf_paths = n_paths;
-    ctx->counts_cap = n_counts;
+    ln.capacity = capacity;
+    ln.paths = n_paths;
+    ln.counts_cap = n_counts;
     return PT_OK;
 }
 
@@ -240,6 +255,18 @@ int pt_context_create(int device, PtContext** out) {
         delete ctx;
         return PT_ERR_HIP;
     }
+    ctx->lanes[0].stream = ctx->stream;
+    for (int l = 1; l < PT_MAX_LANES; ++l) {
+        e = hipStreamCreateWithFlags(&ctx->extra_streams[l - 1], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            g_last_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+            for (int k = 0; k < l - 1; ++k) (void)hipStreamDestroy(ctx->extra_streams[k]);
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return PT_ERR_HIP;
+        }
+        ctx->lanes[l].stream = ctx->extra_streams[l - 1];
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
     *out = ctx;
@@ -250,6 +277,8 @@ void pt_context_destroy(PtContext* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : ctx->extra_streams)
+        if (st) (void)hipStreamSynchronize(st);
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     free_wavefront(ctx);
     free_buf(ctx->d_nodes);
@@ -263,6 +292,8 @@ void pt_context_destroy(PtContext* ctx) {
     free_buf(ctx->d_accum_own);
     free_buf(ctx->d_rgb);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (hipStream_t st : ctx->extra_streams)
+        if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -276,6 +307,13 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
         ctx->paths_per_pass = value;
     } else if (k == "profile") {
         ctx->profile = value ? 1 : 0;
+    } else if (k == "lanes") {  // 2: two half-size sub-passes on two streams, trace of one overlapping shade of the other; 1: serial
+        if (value < 1 || value > PT_MAX_LANES) return ctx->fail(PT_ERR_BAD_ARG, "lanes must be 1..4");
+        ctx->n_lanes = (int)value;
+    } else if (k == "lane_sync") {  // 1: a lane's step waits for the other lane's previous step (lock-step pairing); 0: free-running
+        ctx->lane_sync = value ? 1 : 0;
+    } else if (k == "lane_full_grid") {  // 1: each lane launches the full persistent grid instead of half of it
+        ctx->lane_full_grid = value ? 1 : 0;
     } else if (k == "repack_every") {  // re-deal the surviving rays over the waves every N bounces (0 = never)
         if (value < 0 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "repack_every out of range");
         ctx->repack_every = (int)value;
@@ -623,75 +661,151 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     slots64 = std::min<uint64_t>(slots64, 0xFFFFFFFFull / npix);
     const uint32_t slots = (uint32_t)slots64;
     const uint32_t n_counts = max_bounces + 1;
-    int rc = ensure_wavefront(ctx, (size_t)slots * npix, max_bounces);
-    if (rc != PT_OK) return rc;
+    // Lanes share a pass: the pass's sample slots are dealt out to up to n_lanes independent sub-passes, each on its
+    // own stream with its own buffers, started one pipeline step apart and then free-running, so that the VALU-bound
+    // trace of one lane shares the machine with the memory-bound shade of another.
+    const int n_lanes = (int)std::min<uint32_t>((uint32_t)ctx->n_lanes, slots);
+    LaunchGeom geom = ctx->geom;
+    if (n_lanes > 1 && !ctx->lane_full_grid) geom.grid = std::max<uint32_t>(1u, ctx->geom.grid / (uint32_t)n_lanes);
+    auto lane_share = [](uint32_t total, int lanes, int l) { return total / (uint32_t)lanes + ((uint32_t)l < total % (uint32_t)lanes ? 1u : 0u); };
+    for (int l = 0; l < n_lanes; ++l) {
+        int rc = ensure_lane(ctx, ctx->lanes[l], geom.grid, (size_t)lane_share(slots, n_lanes, l) * npix, max_bounces);
+        if (rc != PT_OK) return rc;
+    }
 
-    PassParams p{};
-    p.width = width;
-    p.height = height;
-    p.npix = npix;
-    p.max_bounces = max_bounces;
-    p.seed = seed;
-    for (int k = 0; k < 3; ++k) p.bg[k] = (float)background[k];
-    p.tiled = (width % 8 == 0 && height % 8 == 0) ? 1 : 0;
+    PassParams base{};
+    base.width = width;
+    base.height = height;
+    base.npix = npix;
+    base.max_bounces = max_bounces;
+    base.seed = seed;
+    for (int k = 0; k < 3; ++k) base.bg[k] = (float)background[k];
+    base.tiled = (width % 8 == 0 && height % 8 == 0) ? 1 : 0;
 
-    // event bookkeeping: ev[k] separates launch k-1 from launch k; kinds[k] = what ran between ev[k] and ev[k+1]
-    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_GAP = 4, K_REPACK = 5 };
-    std::vector<int> kinds;
+    // Event bookkeeping.  Every launch is bracketed by two events on its own stream; the stop event doubles as the
+    // hand-off the other lane waits on.
+    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5 };
+    struct Timed { int kind; size_t start, stop; };
+    std::vector<Timed> timed;
     size_t ev_used = 0;
-    auto mark = [&](int kind_after) -> hipError_t {
-        if (!ctx->profile) return hipSuccess;
+    auto new_event = [&](size_t& idx) -> hipError_t {
         if (ev_used == ctx->events.size()) {
             hipEvent_t ev;
-            hipError_t e = hipEventCreate(&ev);
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDefault);
             if (e != hipSuccess) return e;
             ctx->events.push_back(ev);
         }
-        kinds.push_back(kind_after);
-        return hipEventRecord(ctx->events[ev_used++], ctx->stream);
+        idx = ev_used++;
+        return hipSuccess;
     };
 
-    PT_HIP(ctx, hipMemsetAsync(ctx->wf.totals, 0, (size_t)n_counts * sizeof(unsigned long long), ctx->stream));
-    uint32_t passes = 0, launches_trace = 0, launches_shade = 0;
-    for (uint32_t done = 0; done < sample_count; done += slots) {
-        const uint32_t cur = std::min(slots, sample_count - done);
-        p.n_paths = cur * npix;
-        p.sample_base = sample_begin + done;
-        PT_HIP(ctx, mark(K_RAYGEN));
-        launch_raygen(ctx->stream, ctx->geom, *camera, p, ctx->wf);
-        int buf = 0;                                   // ping-pong buffer holding this bounce's rays
-        const uint32_t* counts_in = ctx->wf.counts;   // row of bounce 0, written by raygen
+    // One lane's pass as a list of steps; step s of lane 1 runs in the same time slot as step s + 1 of lane 0.
+    struct Step { int kind; uint32_t bounce; BounceIO io; };
+    struct LanePlan {
+        PassParams p;
+        uint32_t slots;
+        std::vector<Step> steps;
+        long last_stop = -1;  // event index of the lane's previous step
+    };
+    auto plan_lane = [&](LanePlan& pl, const Wavefront& wf) {
+        pl.steps.clear();
+        pl.steps.push_back({K_RAYGEN, 0, BounceIO{0, 1, nullptr, nullptr}});
+        int buf = 0;
+        const uint32_t* counts_in = wf.counts;
         for (uint32_t b = 0; b < max_bounces; ++b) {
-            BounceIO io{buf, buf ^ 1, counts_in, ctx->wf.counts + count_row(ctx->wf, b + 1)};
-            PT_HIP(ctx, mark(K_TRACE));
-            launch_trace(ctx->stream, ctx->geom, ctx->sc, ctx->wf, io);
-            PT_HIP(ctx, mark(K_SHADE));
-            launch_shade(ctx->stream, ctx->geom, ctx->sc, p, ctx->wf, io, b);
-            ++launches_trace;
-            ++launches_shade;
+            BounceIO io{buf, buf ^ 1, counts_in, wf.counts + count_row(wf, b + 1)};
+            pl.steps.push_back({K_TRACE, b, io});
+            pl.steps.push_back({K_SHADE, b, io});
             buf ^= 1;
             counts_in = io.counts_out;
             const uint32_t every = (uint32_t)ctx->repack_every;
             if (every && b + 1 < max_bounces && b + 1 >= (uint32_t)ctx->repack_first && (b + 1 - ctx->repack_first) % every == 0) {
-                BounceIO rp{buf, buf ^ 1, counts_in, ctx->wf.counts_repacked + count_row(ctx->wf, b + 1)};
-                PT_HIP(ctx, mark(K_REPACK));
-                launch_repack(ctx->stream, ctx->geom, ctx->wf, rp);
+                BounceIO rp{buf, buf ^ 1, counts_in, wf.counts_repacked + count_row(wf, b + 1)};
+                pl.steps.push_back({K_REPACK, b, rp});
                 buf ^= 1;
                 counts_in = rp.counts_out;
             }
         }
-        PT_HIP(ctx, mark(K_FOLD));
-        launch_fold(ctx->stream, p, ctx->wf, cur, ctx->d_accum);
-        PT_HIP(ctx, mark(K_GAP));
-        launch_count_totals(ctx->stream, ctx->wf, max_bounces);
+        pl.steps.push_back({K_FOLD, 0, BounceIO{0, 1, nullptr, nullptr}});
+        pl.steps.push_back({K_TOTALS, 0, BounceIO{0, 1, nullptr, nullptr}});
+    };
+
+    for (int l = 0; l < n_lanes; ++l)
+        PT_HIP(ctx, hipMemsetAsync(ctx->lanes[l].wf.totals, 0, (size_t)n_counts * sizeof(unsigned long long), ctx->lanes[l].stream));
+    size_t ev_begin = 0, ev_end = 0;
+    PT_HIP(ctx, new_event(ev_begin));
+    PT_HIP(ctx, hipEventRecord(ctx->events[ev_begin], ctx->stream));
+    for (int l = 1; l < n_lanes; ++l) PT_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->events[ev_begin], 0));
+
+    uint32_t passes = 0, launches_trace = 0, launches_shade = 0;
+    long fold_guard = -1;  // stop event of the last fold: folds add to the same buffer and must not overlap
+    for (uint32_t done = 0; done < sample_count; done += slots) {
+        const uint32_t cur = std::min(slots, sample_count - done);
+        LanePlan plan[PT_MAX_LANES];
+        const int active = (int)std::min<uint32_t>((uint32_t)n_lanes, cur);
+        uint32_t slot_base = 0;
+        for (int l = 0; l < active; ++l) {
+            plan[l].p = base;
+            plan[l].slots = lane_share(cur, active, l);
+            plan[l].p.n_paths = plan[l].slots * npix;
+            plan[l].p.sample_base = sample_begin + done + slot_base;
+            slot_base += plan[l].slots;
+            plan_lane(plan[l], ctx->lanes[l].wf);
+        }
+        const size_t n_steps = plan[0].steps.size();
+        for (size_t slot = 0; slot < n_steps + (size_t)(active - 1); ++slot) {
+            long stop_of[PT_MAX_LANES];
+            for (int l = 0; l < active; ++l) stop_of[l] = plan[l].last_stop;
+            for (int l = 0; l < active; ++l) {
+                const long si = (long)slot - l;  // lane l starts l steps behind lane 0
+                if (si < 0 || si >= (long)plan[l].steps.size()) continue;
+                const Step& st = plan[l].steps[(size_t)si];
+                PtContext::Lane& ln = ctx->lanes[l];
+                if (active > 1 && (ctx->lane_sync || si == 0)) {
+                    // stagger: a lane's first step (always) and, with lane_sync, every step waits for the previous
+                    // lane's previous step
+                    const int prev = (l + active - 1) % active;
+                    if (plan[prev].last_stop >= 0)
+                        PT_HIP(ctx, hipStreamWaitEvent(ln.stream, ctx->events[(size_t)plan[prev].last_stop], 0));
+                }
+                if (st.kind == K_FOLD && fold_guard >= 0) PT_HIP(ctx, hipStreamWaitEvent(ln.stream, ctx->events[(size_t)fold_guard], 0));
+                Timed t{st.kind, 0, 0};
+                PT_HIP(ctx, new_event(t.start));
+                PT_HIP(ctx, new_event(t.stop));
+                PT_HIP(ctx, hipEventRecord(ctx->events[t.start], ln.stream));
+                switch (st.kind) {
+                    case K_RAYGEN: launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf); break;
+                    case K_TRACE: launch_trace(ln.stream, geom, ctx->sc, ln.wf, st.io); ++launches_trace; break;
+                    case K_SHADE: launch_shade(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_shade; break;
+                    case K_REPACK: launch_repack(ln.stream, geom, ln.wf, st.io); break;
+                    case K_FOLD: launch_fold(ln.stream, plan[l].p, ln.wf, plan[l].slots, ctx->d_accum); break;
+                    default: launch_count_totals(ln.stream, ln.wf, max_bounces); break;
+                }
+                PT_HIP(ctx, hipEventRecord(ctx->events[t.stop], ln.stream));
+                if (st.kind == K_FOLD) fold_guard = (long)t.stop;
+                stop_of[l] = (long)t.stop;
+                timed.push_back(t);
+            }
+            for (int l = 0; l < active; ++l) plan[l].last_stop = stop_of[l];
+        }
         PT_HIP(ctx, hipGetLastError());
         ++passes;
     }
-    PT_HIP(ctx, mark(K_GAP));
-    std::vector<unsigned long long> totals(n_counts, 0);
-    PT_HIP(ctx, hipMemcpyAsync(totals.data(), ctx->wf.totals, (size_t)n_counts * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    // join: lane 0's stream waits for lane 1, then the end marker
+    for (int l = 1; l < n_lanes; ++l) {
+        size_t ej = 0;
+        PT_HIP(ctx, new_event(ej));
+        PT_HIP(ctx, hipEventRecord(ctx->events[ej], ctx->lanes[l].stream));
+        PT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->events[ej], 0));
+    }
+    PT_HIP(ctx, new_event(ev_end));
+    PT_HIP(ctx, hipEventRecord(ctx->events[ev_end], ctx->stream));
+    std::vector<unsigned long long> totals((size_t)n_counts * PT_MAX_LANES, 0);
+    for (int l = 0; l < n_lanes; ++l)
+        PT_HIP(ctx, hipMemcpyAsync(totals.data() + (size_t)l * n_counts, ctx->lanes[l].wf.totals,
+                                   (size_t)n_counts * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 1; l < n_lanes; ++l) PT_HIP(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
 
     if (stats) {
         stats->paths = (uint64_t)npix * sample_count;
@@ -699,16 +813,18 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         stats->launches_trace = launches_trace;
         stats->launches_shade = launches_shade;
         for (uint32_t b = 0; b < max_bounces; ++b) {
-            stats->rays += totals[b];
-            stats->rays_per_bounce[std::min<uint32_t>(b, 63)] += totals[b];
+            unsigned long long v = 0;
+            for (int l = 0; l < n_lanes; ++l) v += totals[(size_t)l * n_counts + b];
+            stats->rays += v;
+            stats->rays_per_bounce[std::min<uint32_t>(b, 63)] += v;
         }
-        if (ctx->profile && ev_used >= 2) {
+        if (ctx->profile) {
             float ms = 0.f;
-            PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[0], ctx->events[ev_used - 1]));
+            PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[ev_begin], ctx->events[ev_end]));
             stats->ms_total = ms;
-            for (size_t k = 0; k + 1 < ev_used; ++k) {
-                PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[k], ctx->events[k + 1]));
-                switch (kinds[k]) {
+            for (const Timed& t : timed) {
+                PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[t.start], ctx->events[t.stop]));
+                switch (t.kind) {
                     case K_RAYGEN: stats->ms_raygen += ms; break;
                     case K_TRACE: stats->ms_trace += ms; break;
                     case K_SHADE: stats->ms_shade += ms; break;

@@ -223,6 +223,34 @@ def test_render_is_deterministic_and_pass_invariant(gpu_ctx, pt):
         gpu_ctx.set_option("paths_per_pass", 1 << 25)
 
 
+def test_scheduling_options_do_not_change_results(gpu_ctx, pt, oracle):
+    # lanes (overlapped sub-passes), repack (re-dealing survivors over the waves) and the persistent-grid size only
+    # change WHERE and WHEN a path is computed: hit-query counts stay exact, images agree to the f32 fold order
+    w, h, spp, depth, seed = 72, 40, 9, 40, 8
+    ctx = pt.Context(0)
+    try:
+        results = []
+        for opts in [dict(lanes=1), dict(lanes=2), dict(lanes=4), dict(lanes=2, lane_sync=1, lane_full_grid=0),
+                     dict(lanes=1, repack_every=1, repack_first=1), dict(lanes=3, repack_every=3, repack_first=2, blocks_per_cu=3),
+                     dict(lanes=2, paths_per_pass=w * h * 4)]:
+            defaults = dict(lanes=2, lane_sync=0, lane_full_grid=1, repack_every=0, repack_first=8, blocks_per_cu=0,
+                            paths_per_pass=1 << 27)
+            for k, v in {**defaults, **opts}.items():
+                ctx.set_option(k, v)
+            s, o = su.named_pair("CornellBox", 1, 1, 1, image=(w, h, spp, depth, (0, 0, 0)))
+            ctx.upload(s)
+            ctx.accum_reset(w, h)
+            st = ctx.render_accumulate(s.camera(0.0), w, h, (0, 0, 0), 0, spp, depth, seed)
+            results.append((st.rays, list(st.rays_per_bounce), ctx.accum_download()))
+        want, rays = o.render_accumulate(s.camera(0.0).as_array(), w, h, (0, 0, 0), 0, spp, depth, seed)
+        for r, rpb, img in results:
+            assert r == rays and rpb == results[0][1]
+            assert np.allclose(img, results[0][2], rtol=1e-5, atol=1e-5)
+            assert_images_close(img.astype(np.float64), want, spp)
+    finally:
+        ctx.close()
+
+
 def test_depth_zero_and_background(gpu_ctx, pt):
     s = pt.Scene("TwoSpheres").set_image(16, 8, 2, 3, (1, 1, 1)).build()
     gpu_ctx.upload(s)
