@@ -193,6 +193,9 @@ void* pt_accum_device_ptr(PtContext* ctx);
 /* Device-side checks of the arithmetic the parity contract leans on (IEEE division and sqrt, the Philox
  * stream): computes a[i]/b[i] and sqrt(|a[i]|) on the GPU for host arrays of n doubles. */
 int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root);
+/* a[i]/b[i] as the lockstep trace kernel forms its rectangle quotients (from the correctly rounded reciprocal, one
+ * FMA residual and one correction, with the IEEE division as the fallback): must equal pt_selftest_arith's quot. */
+int pt_selftest_division(PtContext* ctx, const double* a, const double* b, size_t n, double* quot);
 /* First n draws of stream (seed, pixel, sample, stream) as produced on the GPU. */
 int pt_selftest_rng(PtContext* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out);
 /* Texture.value (texture.rs:5-7) of texture `tex` of the uploaded scene at n points (host arrays). */

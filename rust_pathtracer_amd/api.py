@@ -177,6 +177,7 @@ _PTGPU_PROTOS = {
     "pt_accum_upload": (C.c_int, [_vp, _vp]),
     "pt_accum_device_ptr": (_vp, [_vp]),
     "pt_selftest_arith": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "pt_selftest_division": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "pt_selftest_rng": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pt_selftest_texture": (C.c_int, [_vp, C.c_uint32, _vp, C.c_size_t, _vp]),
 }
@@ -435,6 +436,13 @@ class Context:
         q, r = np.empty_like(a), np.empty_like(a)
         self._ok(libptgpu.pt_selftest_arith(self._h, a.ctypes.data, b.ctypes.data, a.size, q.ctypes.data, r.ctypes.data))
         return q, r
+
+    def selftest_division(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        q = np.empty_like(a)
+        self._ok(libptgpu.pt_selftest_division(self._h, a.ctypes.data, b.ctypes.data, a.size, q.ctypes.data))
+        return q
 
     def selftest_rng(self, seed, pixel, sample, stream, n) -> np.ndarray:
         out = np.empty(n, dtype=np.float64)

@@ -53,8 +53,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 #endif
 #pragma unroll
     for (int r = 0; r < PT_PHILOX_ROUNDS; ++r) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of separate low and high multiplies
+        uint64_t p0 = (uint64_t)c0 * 0xD2511F53ull, p1 = (uint64_t)c2 * 0xCD9E8D57ull;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0;
         uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -345,9 +347,53 @@ __device__ __forceinline__ bool walk_aabb(const double* b, V3 o, V3 inv, double 
     miss |= t_max <= t_min;
     return !miss;
 }
-__device__ __forceinline__ bool walk_rect(const double* g, double on, double dn, double oa, double da, double ob, double db,
-                                          double t_min, double t_max, double& t_out) { // geometry.rs:210-221 etc.
-    double t = (g[0] - on) / dn;
+// true when the predicate holds in any active lane: the lane mask compared as a scalar (HIP's __any goes through a
+// VGPR select and compare)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+
+// n / d, correctly rounded, given y = 1.0 / d (itself correctly rounded): one product, the exact residual by FMA and one
+// correction (Markstein's theorem) -- mul, fma, fma (full rate) instead of the 11-instruction, ~58-cycle IEEE sequence.
+// The shortcut is only taken where its proof holds:
+//   * y is a normal number of magnitude >= 2^-150 (reciprocal_for_division hands out NaN otherwise: d = 0, infinite,
+//     NaN, denormal or astronomically large);
+//   * |n| > 2^-900, so the residual n - q*d cannot underflow and is exact, and the first quotient q = n*y is a normal
+//     number; or n is +0, where every step yields the correctly signed zero.  (A ray leaving an axis-aligned rectangle
+//     starts exactly on its plane, so n = +0 is the common special case and must not leave the fast path.)
+// A wave in which any lane falls outside takes the ordinary division, so the result is n / d bit for bit in every case
+// (tests: pt_selftest_division against pt_selftest_arith, and every bit-exact hit comparison).
+#ifndef PT_NO_FAST_DIV
+__device__ __forceinline__ double reciprocal_for_division(double y) {
+    return (fabs(y) >= 0x1p-150 && fabs(y) <= 0x1.fffffffffffffp1023) ? y : __builtin_nan("");
+}
+// lanes of the wave whose x is in the IEEE classes of `classes` (v_cmp_class bit set), as a scalar mask
+__device__ __forceinline__ unsigned long long wave_class_mask(double x, uint32_t classes) {
+    unsigned long long m;
+    asm("v_cmp_class_f64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(classes));
+    return m;
+}
+__device__ __forceinline__ double div_given_reciprocal(double n, double d, double y) {
+    double q = n * y;
+    const unsigned long long q_ok = wave_class_mask(q, 0x168u);   // +-normal, +-0
+    const unsigned long long n_zero = wave_class_mask(n, 0x40u);  // +0
+    const unsigned long long n_big = __builtin_amdgcn_ballot_w64(fabs(n) > 0x1p-900);
+    if (__builtin_expect((q_ok & (n_big | n_zero)) != __builtin_amdgcn_ballot_w64(true), 0)) {
+        asm volatile("; IEEE division fallback" : "+v"(n)); // keeps this a real (wave-uniform) branch: never speculated
+        q = n / d;
+    } else {
+        double r = __builtin_fma(-q, d, n);
+        q = __builtin_fma(r, y, q);
+    }
+    return q;
+}
+#else
+__device__ __forceinline__ double reciprocal_for_division(double y) { return y; }
+__device__ __forceinline__ double div_given_reciprocal(double n, double d, double) { return n / d; }
+#endif
+
+__device__ __forceinline__ bool walk_rect(const double* g, double on, double dn, double inv_dn, double oa, double da, double ob,
+                                          double db, double t_min, double t_max, double& t_out) { // geometry.rs:210-221 etc.
+    double t = div_given_reciprocal(g[0] - on, dn, inv_dn);
     bool out = (t < t_min) | (t > t_max);
     double a = oa + t * da;
     double b = ob + t * db;
@@ -363,12 +409,12 @@ __device__ __forceinline__ bool walk_sphere(const double* g, bool act, V3 o, V3 
     double dis = half_b * half_b - a * c;
     bool cand = act & !(dis < 0.0);
     bool hit = false;
-    if (__any(cand)) { // wave-uniform: skip the sqrt and divides when the whole wave misses
+    if (wave_any(cand)) { // wave-uniform: skip the sqrt and divides when the whole wave misses
         double sq = sqrt(dis);
         double root = (-half_b - sq) / a;
         bool out1 = (root < t_min) | (root > t_max);
         hit = cand & !out1;
-        if (__any(cand & out1)) {
+        if (wave_any(cand & out1)) {
             double root2 = (-half_b + sq) / a;
             bool out2 = (root2 < t_min) | (root2 > t_max);
             if (out1) root = root2;
@@ -385,7 +431,7 @@ __device__ __forceinline__ bool walk_triangle(const double* g, bool act, V3 o, V
     double det = dot(v0v1, pvec);
     bool cand = act & !(det < 0.0001);
     bool hit = false;
-    if (__any(cand)) {
+    if (wave_any(cand)) {
         double inv_det = 1.0 / det;
         V3 tvec = o - v3(g[0], g[1], g[2]);
         double u = dot(tvec, pvec) * inv_det;
@@ -404,6 +450,7 @@ __device__ __forceinline__ bool walk_triangle(const double* g, bool act, V3 o, V
 __device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk, uint32_t n_walk, bool lane_live, V3 o, V3 d,
                                               double t_min, double t_max, double& best_t, int32_t& best_prim) {
     V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    V3 rcp = v3(reciprocal_for_division(inv.x), reciprocal_for_division(inv.y), reciprocal_for_division(inv.z));
     best_t = t_max;
     best_prim = -1;
     uint32_t skip_until = lane_live ? 0u : 0xFFFFFFFFu;
@@ -417,16 +464,16 @@ __device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk,
         if (kind == 0u) {
             bool hit = act & walk_aabb(it.d, o, inv, t_min, best_t);
             if (act & !hit) skip_until = aux;
-            i = __any(hit) ? i + 1u : aux;
+            i = wave_any(hit) ? i + 1u : aux;
         } else {
-            if (__any(act)) {
+            if (wave_any(act)) {
                 double t = 0.0;
                 bool h;
                 switch (kind - 1u) { // wave-uniform: a scalar branch
                     case PT_PRIM_SPHERE: h = walk_sphere(it.d, act, o, d, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_XY: h = act & walk_rect(it.d, o.z, d.z, o.x, d.x, o.y, d.y, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_XZ: h = act & walk_rect(it.d, o.y, d.y, o.x, d.x, o.z, d.z, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_YZ: h = act & walk_rect(it.d, o.x, d.x, o.y, d.y, o.z, d.z, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_XY: h = act & walk_rect(it.d, o.z, d.z, rcp.z, o.x, d.x, o.y, d.y, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_XZ: h = act & walk_rect(it.d, o.y, d.y, rcp.y, o.x, d.x, o.z, d.z, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_YZ: h = act & walk_rect(it.d, o.x, d.x, rcp.x, o.y, d.y, o.z, d.z, t_min, best_t, t); break;
                     default: h = walk_triangle(it.d, act, o, d, t_min, best_t, t); break;
                 }
                 if (h) {

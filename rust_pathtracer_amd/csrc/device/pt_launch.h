@@ -61,6 +61,6 @@ void launch_count_totals(hipStream_t s, const Wavefront& wf, uint32_t n_bounces)
 void launch_resolve(hipStream_t s, const float* accum, uint32_t n_values, uint32_t total_spp, uint8_t* rgb);
 void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const double* origins, const double* dirs,
                         uint32_t n, double t_min, double t_max, PtHitOut* out);
-void launch_selftest_arith(hipStream_t s, const double* a, const double* b, uint32_t n, double* quot, double* root);
+void launch_selftest_arith(hipStream_t s, const double* a, const double* b, uint32_t n, double* quot, double* root, int via_reciprocal);
 void launch_selftest_rng(hipStream_t s, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out);
 void launch_selftest_texture(hipStream_t s, const DevScene& sc, uint32_t tex, const double* points, uint32_t n, double* rgb);

@@ -873,7 +873,7 @@ int pt_accum_upload(PtContext* ctx, const float* rgb_sum) {
     return PT_OK;
 }
 
-int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root) {
+static int selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root, int via_reciprocal) {
     if (!ctx) return PT_ERR_BAD_ARG;
     if (!a || !b || !quot || !root || n == 0 || n > ((size_t)1 << 26)) return ctx->fail(PT_ERR_BAD_ARG, "pt_selftest_arith: bad argument");
     PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -885,7 +885,8 @@ int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n
     if (e == hipSuccess) e = hipMemcpyAsync(da.p, a, n * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db.p, b, n * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        launch_selftest_arith(ctx->stream, (const double*)da.p, (const double*)db.p, (uint32_t)n, (double*)dq.p, (double*)dr.p);
+        launch_selftest_arith(ctx->stream, (const double*)da.p, (const double*)db.p, (uint32_t)n, (double*)dq.p, (double*)dr.p,
+                              via_reciprocal);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(quot, dq.p, n * 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -897,6 +898,15 @@ int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n
     free_buf(dr);
     if (e != hipSuccess) return ctx->fail_hip("pt_selftest_arith", e);
     return PT_OK;
+}
+int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root) {
+    return selftest_arith(ctx, a, b, n, quot, root, 0);
+}
+int pt_selftest_division(PtContext* ctx, const double* a, const double* b, size_t n, double* quot) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!quot || n == 0 || n > ((size_t)1 << 26)) return ctx->fail(PT_ERR_BAD_ARG, "pt_selftest_division: bad argument");
+    std::vector<double> root(n);
+    return selftest_arith(ctx, a, b, n, quot, root.data(), 1);
 }
 
 int pt_selftest_rng(PtContext* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out) {

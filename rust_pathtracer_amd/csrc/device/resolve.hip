@@ -67,15 +67,20 @@ void launch_resolve(hipStream_t s, const float* accum, uint32_t n_values, uint32
 }
 
 // ---- device-side checks of the arithmetic the parity contract leans on
-__global__ void selftest_arith_kernel(const double* a, const double* b, uint32_t n, double* quot, double* root) {
+// via_reciprocal: the quotient as the lockstep walk forms it (div_given_reciprocal); n is padded to whole waves by the
+// caller's grid, and every lane of a wave takes part in the wave-wide fallback vote.
+__global__ void selftest_arith_kernel(const double* a, const double* b, uint32_t n, double* quot, double* root, int via_reciprocal) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        quot[i] = a[i] / b[i];
-        root[i] = sqrt(fabs(a[i]));
+    const bool live = i < n;
+    const double x = live ? a[i] : 1.0, y = live ? b[i] : 1.0;
+    const double q = via_reciprocal ? div_given_reciprocal(x, y, reciprocal_for_division(1.0 / y)) : x / y;
+    if (live) {
+        quot[i] = q;
+        root[i] = sqrt(fabs(x));
     }
 }
-void launch_selftest_arith(hipStream_t s, const double* a, const double* b, uint32_t n, double* quot, double* root) {
-    hipLaunchKernelGGL(selftest_arith_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, quot, root);
+void launch_selftest_arith(hipStream_t s, const double* a, const double* b, uint32_t n, double* quot, double* root, int via_reciprocal) {
+    hipLaunchKernelGGL(selftest_arith_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, n, quot, root, via_reciprocal);
 }
 __global__ void selftest_rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {

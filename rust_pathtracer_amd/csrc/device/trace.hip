@@ -55,7 +55,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __
         const uint32_t k = first + (threadIdx.x & 63u);
         const bool live = k < n;
         const size_t i = base + k;
-        double2 a = make_double2(0, 0), b = make_double2(0, 1), c = make_double2(0, 0);
+        // idle lanes carry an ordinary ray (finite reciprocals, nonzero plane offsets): they take part in the wave-wide
+        // votes of the walk (div_given_reciprocal) and must not drag the wave onto its slow path
+        double2 a = make_double2(0x1p40, 0x1p40), b = make_double2(0x1p40, 1), c = make_double2(1, 1);
         if (live) {
             a = rays.a[i];
             b = rays.b[i];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_walk_kernel(DevScene sc,
     for (uint32_t base = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); base < n; base += stride) {
         const uint32_t i = base + (threadIdx.x & 63u);
         const bool live = i < n;
-        V3 o = v3(0, 0, 0), d = v3(1, 0, 0);
+        V3 o = v3(0x1p40, 0x1p40, 0x1p40), d = v3(1, 1, 1); // idle lanes: an ordinary ray (see trace_walk_kernel)
         if (live) {
             o = v3(origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]);
             d = v3(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]);

@@ -44,6 +44,34 @@ def test_device_division_and_sqrt_are_correctly_rounded(gpu_ctx):
         assert np.array_equal(r, np.sqrt(np.abs(a)), equal_nan=True)
 
 
+def test_device_quotient_from_reciprocal_equals_division(gpu_ctx):
+    """The lockstep walk forms (k - o)/d from the ray's 1/d (pt_device.h div_given_reciprocal); that must be the
+    IEEE quotient bit for bit: whole waves of ordinary values (the shortcut proper), hard mantissas next to 1 and 2,
+    and waves salted with zeros, infinities, NaNs, denormals and huge/tiny magnitudes (the fallback vote)."""
+    rng = np.random.default_rng(1)
+    n = 1 << 20
+    a = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)
+    b = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6, n)
+    eps = 2.0 ** -52
+    k = np.arange(1 << 16)
+    a[: 1 << 16] = 1.0 + (k % 256) * eps
+    b[: 1 << 16] = 2.0 - (1 + k // 256) * eps
+    a[1 << 16 : 1 << 17] = 2.0 - (1 + k % 256) * eps
+    b[1 << 16 : 1 << 17] = 1.0 + (k // 256) * eps
+    a[1 << 17 : 3 << 16] = rng.integers(1, 100000, 1 << 16)  # exact and near-exact integer ratios
+    b[1 << 17 : 3 << 16] = rng.integers(1, 100000, 1 << 16)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -3e-310, 1e-305, 1e300, -1e308, 2.0 ** -1000, 3.0, 1.0, -7.5])
+    tail = n - (1 << 18)
+    a[tail:] = np.where(rng.random(n - tail) < 0.1, rng.choice(special, n - tail), a[tail:])
+    b[tail:] = np.where(rng.random(n - tail) < 0.1, rng.choice(special, n - tail), b[tail:])
+    with np.errstate(all="ignore"):
+        want = a / b
+    got = gpu_ctx.selftest_division(a, b)
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(got), ~ok)
+    assert np.array_equal(got[ok].view(np.uint64), want[ok].view(np.uint64))  # zeros keep their sign
+
+
 def test_device_rng_stream_matches_oracle(gpu_ctx, oracle):
     for seed, pixel, sample, stream in [(1, 0, 0, 0), (0x1234567890ABCDEF, 17, 3, 2), (2 ** 64 - 1, 2 ** 32 - 1, 1023, 51)]:
         assert np.array_equal(gpu_ctx.selftest_rng(seed, pixel, sample, stream, 33), oracle.sample_draws(seed, pixel, sample, stream, 33))
