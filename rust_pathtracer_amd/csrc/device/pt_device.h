@@ -172,6 +172,7 @@ struct DevScene {
     uint32_t stack_depth;
     const WalkItem* walk; // non-null when the scene is small enough for the wave-uniform walk
     uint32_t n_walk;
+    uint32_t walk_flags; // PT_WALK_*
     uint32_t has_procedural; // any checker / marble texture
     const ShadePrim* shade_prims;
 };
@@ -328,131 +329,154 @@ __device__ __forceinline__ void traverse(const DevScene& sc, const DevNode* lds_
 // subtree the whole wave jumps over it.  Per lane this performs exactly the sequence of box and primitive
 // tests, with the same running t_max, as the stack walk above and as the reference recursion.
 // Straight-line (predicated) forms of the tests for the lockstep walk: every comparison of the reference is kept
-// as written (so NaNs fall the same way), only the early returns are folded into one boolean.
-__device__ __forceinline__ bool walk_aabb(const double* b, V3 o, V3 inv, double t_min, double t_max) { // bvh.rs:18-35
+// as written (so NaNs fall the same way), only the early returns are folded together.  Each comparison goes
+// straight into a 64-bit lane mask in SGPRs (one v_cmp each), the masks are combined by the scalar unit, and a
+// mask comes back as a per-lane predicate only where a lane-wise select needs it -- no VGPR round trips.
+typedef unsigned long long LaneMask;
+__device__ __forceinline__ LaneMask lanes_where(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_in(LaneMask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+__device__ __forceinline__ bool wave_any(bool p) { return lanes_where(p) != 0ull; }
+
+// lanes whose ray misses the box (bvh.rs:18-35)
+__device__ __forceinline__ LaneMask walk_aabb_miss(const double* b, V3 o, V3 inv, double t_min, double t_max) {
     double t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
     double lo = (inv.x < 0.0) ? t1 : t0, hi = (inv.x < 0.0) ? t0 : t1;
     t_min = fmax(lo, t_min);
     t_max = fmin(hi, t_max);
-    bool miss = t_max <= t_min;
+    LaneMask miss = lanes_where(t_max <= t_min);
     t0 = (b[1] - o.y) * inv.y; t1 = (b[4] - o.y) * inv.y;
     lo = (inv.y < 0.0) ? t1 : t0; hi = (inv.y < 0.0) ? t0 : t1;
     t_min = fmax(lo, t_min);
     t_max = fmin(hi, t_max);
-    miss |= t_max <= t_min;
+    miss |= lanes_where(t_max <= t_min);
     t0 = (b[2] - o.z) * inv.z; t1 = (b[5] - o.z) * inv.z;
     lo = (inv.z < 0.0) ? t1 : t0; hi = (inv.z < 0.0) ? t0 : t1;
     t_min = fmax(lo, t_min);
     t_max = fmin(hi, t_max);
-    miss |= t_max <= t_min;
-    return !miss;
+    miss |= lanes_where(t_max <= t_min);
+    return miss;
 }
-// true when the predicate holds in any active lane: the lane mask compared as a scalar (HIP's __any goes through a
-// VGPR select and compare)
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 
-// n / d, correctly rounded, given y = 1.0 / d (itself correctly rounded): one product, the exact residual by FMA and one
-// correction (Markstein's theorem) -- mul, fma, fma (full rate) instead of the 11-instruction, ~58-cycle IEEE sequence.
-// The shortcut is only taken where its proof holds:
-//   * y is a normal number of magnitude >= 2^-150 (reciprocal_for_division hands out NaN otherwise: d = 0, infinite,
-//     NaN, denormal or astronomically large);
-//   * |n| > 2^-900, so the residual n - q*d cannot underflow and is exact, and the first quotient q = n*y is a normal
-//     number; or n is +0, where every step yields the correctly signed zero.  (A ray leaving an axis-aligned rectangle
-//     starts exactly on its plane, so n = +0 is the common special case and must not leave the fast path.)
-// A wave in which any lane falls outside takes the ordinary division, so the result is n / d bit for bit in every case
-// (tests: pt_selftest_division against pt_selftest_arith, and every bit-exact hit comparison).
-#ifndef PT_NO_FAST_DIV
+// ---- n / d from the ray's reciprocal.
+// Given y = 1.0 / d correctly rounded, q0 = n*y, r = fma(-q0, d, n) (the exact residual) and q = fma(r, y, q0) is
+// n / d correctly rounded (Markstein's theorem): mul, fma, fma at full rate instead of the 11-instruction, ~58-cycle
+// IEEE sequence (profiles/r01_instruction_rates.txt).  The proof needs y and q0 to be normal numbers and the residual
+// not to underflow; n = +0 also works (every step gives the correctly signed zero), and it is the common special
+// case: a ray leaving an axis-aligned rectangle starts exactly on its plane.
+//   div_given_reciprocal  checks those conditions per quotient and lets the wave vote: any lane outside them sends the
+//                         whole wave through the IEEE division.  Result = n / d bit for bit for ALL inputs.
+//   div_proven            the three instructions alone, for callers that have established the conditions up front
+//                         (traverse_walk does so once per ray batch, see walk_division_is_proven).
+// Tests: pt_selftest_division against pt_selftest_arith; every bit-exact hit comparison, including rays and planes of
+// extreme magnitude (tests/test_gpu_parity.py).
+__device__ __forceinline__ bool reciprocal_in_range(double y) { return fabs(y) >= 0x1p-150 && fabs(y) <= 0x1p150; }
 __device__ __forceinline__ double reciprocal_for_division(double y) {
-    return (fabs(y) >= 0x1p-150 && fabs(y) <= 0x1.fffffffffffffp1023) ? y : __builtin_nan("");
+    return reciprocal_in_range(y) ? y : __builtin_nan("");
 }
 // lanes of the wave whose x is in the IEEE classes of `classes` (v_cmp_class bit set), as a scalar mask
-__device__ __forceinline__ unsigned long long wave_class_mask(double x, uint32_t classes) {
-    unsigned long long m;
+__device__ __forceinline__ LaneMask wave_class_mask(double x, uint32_t classes) {
+    LaneMask m;
     asm("v_cmp_class_f64 %0, %1, %2" : "=s"(m) : "v"(x), "s"(classes));
     return m;
 }
-__device__ __forceinline__ double div_given_reciprocal(double n, double d, double y) {
+__device__ __forceinline__ double div_proven(double n, double d, double y) {
     double q = n * y;
-    const unsigned long long q_ok = wave_class_mask(q, 0x168u);   // +-normal, +-0
-    const unsigned long long n_zero = wave_class_mask(n, 0x40u);  // +0
-    const unsigned long long n_big = __builtin_amdgcn_ballot_w64(fabs(n) > 0x1p-900);
-    if (__builtin_expect((q_ok & (n_big | n_zero)) != __builtin_amdgcn_ballot_w64(true), 0)) {
-        asm volatile("; IEEE division fallback" : "+v"(n)); // keeps this a real (wave-uniform) branch: never speculated
-        q = n / d;
-    } else {
-        double r = __builtin_fma(-q, d, n);
-        q = __builtin_fma(r, y, q);
-    }
-    return q;
+    double r = __builtin_fma(-q, d, n);
+    return __builtin_fma(r, y, q);
 }
-#else
-__device__ __forceinline__ double reciprocal_for_division(double y) { return y; }
-__device__ __forceinline__ double div_given_reciprocal(double n, double d, double) { return n / d; }
-#endif
+__device__ __forceinline__ double div_ieee_unspeculated(double n, double d) {
+    asm volatile("; IEEE division" : "+v"(n)); // pins the division inside its (wave-uniform) branch: never hoisted
+    return n / d;
+}
+__device__ __forceinline__ double div_given_reciprocal(double n, double d, double y) {
+    y = reciprocal_for_division(y);
+    const double q = n * y;
+    const LaneMask q_ok = wave_class_mask(q, 0x168u);   // +-normal, +-0
+    const LaneMask n_zero = wave_class_mask(n, 0x40u);  // +0
+    const LaneMask n_big = lanes_where(fabs(n) > 0x1p-900);
+    if (__builtin_expect((q_ok & (n_big | n_zero)) != lanes_where(true), 0)) return div_ieee_unspeculated(n, d);
+    return div_proven(n, d, y);
+}
+// The conditions of div_proven for every rectangle quotient (k - o_c) / d_c of a ray, established once per ray:
+//   scene (checked at upload, PT_WALK_PLANES_IN_RANGE): every rectangle plane k is 0 or 2^-800 <= |k| <= 2^400;
+//   ray: each origin component is 0 or in that same range, each reciprocal 1/d_c is in [2^-150, 2^150].
+// Then n = k - o_c is +-0 or 2^-853 <= |n| <= 2^401 (a nonzero difference of two such numbers is at least half an ulp of
+// the larger), q0 = n*y is 0 or in [2^-1003, 2^551]: normal, and the residual, a multiple of ulp(q0)*ulp(d) >= 2^-957,
+// is exact.  (n = -0 needs k = -0, o_c = +0; the quotient may then come out as +0 instead of -0, which no comparison
+// and no consumer of t distinguishes.)
+__device__ __forceinline__ bool coordinate_in_range(double c) { return c == 0.0 || (fabs(c) >= 0x1p-800 && fabs(c) <= 0x1p400); }
+__device__ __forceinline__ bool walk_division_is_proven(V3 o, V3 inv) {
+    const bool ok = reciprocal_in_range(inv.x) && reciprocal_in_range(inv.y) && reciprocal_in_range(inv.z) &&
+                    coordinate_in_range(o.x) && coordinate_in_range(o.y) && coordinate_in_range(o.z);
+    return lanes_where(ok) == lanes_where(true);
+}
+#define PT_WALK_PLANES_IN_RANGE 1u
 
-__device__ __forceinline__ bool walk_rect(const double* g, double on, double dn, double inv_dn, double oa, double da, double ob,
-                                          double db, double t_min, double t_max, double& t_out) { // geometry.rs:210-221 etc.
-    double t = div_given_reciprocal(g[0] - on, dn, inv_dn);
-    bool out = (t < t_min) | (t > t_max);
+// lanes that do NOT hit the rectangle (geometry.rs:210-221 and the XZ / YZ twins); t for all lanes
+template <bool PROVEN>
+__device__ __forceinline__ LaneMask walk_rect_out(const double* g, double on, double dn, double inv_dn, double oa, double da,
+                                                  double ob, double db, double t_min, double t_max, double& t_out) {
+#ifdef PT_NO_FAST_DIV
+    double t = (g[0] - on) / dn;
+#else
+    double t = PROVEN ? div_proven(g[0] - on, dn, inv_dn) : div_ieee_unspeculated(g[0] - on, dn);
+#endif
+    LaneMask out = lanes_where(t < t_min) | lanes_where(t > t_max);
     double a = oa + t * da;
     double b = ob + t * db;
-    out |= (a < g[1]) | (a > g[2]) | (b < g[3]) | (b > g[4]);
+    out |= lanes_where(a < g[1]) | lanes_where(a > g[2]) | lanes_where(b < g[3]) | lanes_where(b > g[4]);
     t_out = t;
-    return !out;
+    return out;
 }
-__device__ __forceinline__ bool walk_sphere(const double* g, bool act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+__device__ __forceinline__ LaneMask walk_sphere(const double* g, LaneMask act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
     V3 oc = o - v3(g[0], g[1], g[2]); // geometry.rs:132-148
     double a = len_squared(d);
     double half_b = dot(d, oc);
     double c = len_squared(oc) - g[3] * g[3];
     double dis = half_b * half_b - a * c;
-    bool cand = act & !(dis < 0.0);
-    bool hit = false;
-    if (wave_any(cand)) { // wave-uniform: skip the sqrt and divides when the whole wave misses
+    const LaneMask cand = act & ~lanes_where(dis < 0.0);
+    LaneMask hit = 0;
+    if (cand) { // wave-uniform: skip the sqrt and divides when the whole wave misses
         double sq = sqrt(dis);
         double root = (-half_b - sq) / a;
-        bool out1 = (root < t_min) | (root > t_max);
-        hit = cand & !out1;
-        if (wave_any(cand & out1)) {
+        const LaneMask out1 = lanes_where(root < t_min) | lanes_where(root > t_max);
+        hit = cand & ~out1;
+        if (cand & out1) {
             double root2 = (-half_b + sq) / a;
-            bool out2 = (root2 < t_min) | (root2 > t_max);
-            if (out1) root = root2;
-            hit = cand & !(out1 & out2);
+            const LaneMask out2 = lanes_where(root2 < t_min) | lanes_where(root2 > t_max);
+            if (lane_in(out1)) root = root2;
+            hit = cand & ~(out1 & out2);
         }
         t_out = root;
     }
     return hit;
 }
-__device__ __forceinline__ bool walk_triangle(const double* g, bool act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+__device__ __forceinline__ LaneMask walk_triangle(const double* g, LaneMask act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
     V3 v0v1 = v3(g[3], g[4], g[5]); // geometry.rs:519-546
     V3 v0v2 = v3(g[6], g[7], g[8]);
     V3 pvec = cross(d, v0v2);
     double det = dot(v0v1, pvec);
-    bool cand = act & !(det < 0.0001);
-    bool hit = false;
-    if (wave_any(cand)) {
+    const LaneMask cand = act & ~lanes_where(det < 0.0001);
+    LaneMask hit = 0;
+    if (cand) {
         double inv_det = 1.0 / det;
         V3 tvec = o - v3(g[0], g[1], g[2]);
         double u = dot(tvec, pvec) * inv_det;
-        bool ok = cand & ((u >= 0.0) & (u <= 1.0));
+        LaneMask ok = cand & lanes_where(u >= 0.0) & lanes_where(u <= 1.0);
         V3 qvec = cross(tvec, v0v1);
         double v = dot(d, qvec) * inv_det;
-        ok &= !((v < 0.0) | (u + v > 1.0));
+        ok &= ~(lanes_where(v < 0.0) | lanes_where(u + v > 1.0));
         double t = dot(v0v2, qvec) * inv_det;
-        ok &= (t >= t_min) & (t <= t_max);
+        ok &= lanes_where(t >= t_min) & lanes_where(t <= t_max);
         t_out = t;
         hit = ok;
     }
     return hit;
 }
 
-__device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk, uint32_t n_walk, bool lane_live, V3 o, V3 d,
-                                              double t_min, double t_max, double& best_t, int32_t& best_prim) {
-    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-    V3 rcp = v3(reciprocal_for_division(inv.x), reciprocal_for_division(inv.y), reciprocal_for_division(inv.z));
-    best_t = t_max;
-    best_prim = -1;
+template <bool PROVEN>
+__device__ __forceinline__ void traverse_walk_loop(const WalkItem* __restrict__ walk, uint32_t n_walk, bool lane_live, V3 o, V3 d,
+                                                   V3 inv, double t_min, double& best_t, int32_t& best_prim) {
     uint32_t skip_until = lane_live ? 0u : 0xFFFFFFFFu;
     uint32_t i = 0;
     while (i < n_walk) {
@@ -460,23 +484,23 @@ __device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk,
         const WalkItem it = walk[i]; // one 80-byte scalar fetch per step
         const uint32_t kind = it.kind;
         const uint32_t aux = it.aux;
-        const bool act = skip_until <= i;
+        const LaneMask act = lanes_where(skip_until <= i);
         if (kind == 0u) {
-            bool hit = act & walk_aabb(it.d, o, inv, t_min, best_t);
-            if (act & !hit) skip_until = aux;
-            i = wave_any(hit) ? i + 1u : aux;
+            const LaneMask miss = walk_aabb_miss(it.d, o, inv, t_min, best_t);
+            if (lane_in(act & miss)) skip_until = aux;
+            i = (act & ~miss) ? i + 1u : aux;
         } else {
-            if (wave_any(act)) {
+            if (act) {
                 double t = 0.0;
-                bool h;
+                LaneMask h;
                 switch (kind - 1u) { // wave-uniform: a scalar branch
                     case PT_PRIM_SPHERE: h = walk_sphere(it.d, act, o, d, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_XY: h = act & walk_rect(it.d, o.z, d.z, rcp.z, o.x, d.x, o.y, d.y, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_XZ: h = act & walk_rect(it.d, o.y, d.y, rcp.y, o.x, d.x, o.z, d.z, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_YZ: h = act & walk_rect(it.d, o.x, d.x, rcp.x, o.y, d.y, o.z, d.z, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_XY: h = act & ~walk_rect_out<PROVEN>(it.d, o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_XZ: h = act & ~walk_rect_out<PROVEN>(it.d, o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, best_t, t); break;
+                    case PT_PRIM_RECT_YZ: h = act & ~walk_rect_out<PROVEN>(it.d, o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, best_t, t); break;
                     default: h = walk_triangle(it.d, act, o, d, t_min, best_t, t); break;
                 }
-                if (h) {
+                if (lane_in(h)) {
                     best_t = t;
                     best_prim = (int32_t)aux;
                 }
@@ -484,6 +508,17 @@ __device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk,
             i = i + 1u;
         }
     }
+}
+
+__device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk, uint32_t n_walk, uint32_t walk_flags, bool lane_live,
+                                              V3 o, V3 d, double t_min, double t_max, double& best_t, int32_t& best_prim) {
+    V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    best_t = t_max;
+    best_prim = -1;
+    if ((walk_flags & PT_WALK_PLANES_IN_RANGE) && walk_division_is_proven(o, inv))
+        traverse_walk_loop<true>(walk, n_walk, lane_live, o, d, inv, t_min, best_t, best_prim);
+    else
+        traverse_walk_loop<false>(walk, n_walk, lane_live, o, d, inv, t_min, best_t, best_prim);
 }
 
 // Outward normal of primitive `prim` at point p: geometry.rs:151 (sphere), :227/:290/:353 (rectangles),

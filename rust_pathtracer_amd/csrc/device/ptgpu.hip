@@ -552,6 +552,16 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.stack_depth = tc.max_depth;
     sc.walk = walk.empty() ? nullptr : (const WalkItem*)ctx->d_walk.p;
     sc.n_walk = (uint32_t)walk.size();
+    // the lockstep walk forms rectangle quotients from the ray's reciprocal when every plane coordinate is 0 or of
+    // ordinary magnitude (pt_device.h walk_division_is_proven); any other scene keeps the IEEE division
+    sc.walk_flags = PT_WALK_PLANES_IN_RANGE;
+    for (const WalkItem& it : walk) {
+        const uint32_t type = it.kind - 1u;
+        if (it.kind != 0u && (type == PT_PRIM_RECT_XY || type == PT_PRIM_RECT_XZ || type == PT_PRIM_RECT_YZ)) {
+            const double k = std::fabs(it.d[0]);
+            if (!(k == 0.0 || (k >= 0x1p-800 && k <= 0x1p400))) sc.walk_flags = 0;
+        }
+    }
     sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
     sc.has_procedural = 0;
     for (uint32_t i = 0; i < s->n_textures; ++i)

@@ -73,7 +73,7 @@ __global__ void selftest_arith_kernel(const double* a, const double* b, uint32_t
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     const double x = live ? a[i] : 1.0, y = live ? b[i] : 1.0;
-    const double q = via_reciprocal ? div_given_reciprocal(x, y, reciprocal_for_division(1.0 / y)) : x / y;
+    const double q = via_reciprocal ? div_given_reciprocal(x, y, 1.0 / y) : x / y;
     if (live) {
         quot[i] = q;
         root[i] = sqrt(fabs(x));
