@@ -131,16 +131,22 @@ struct DevPrim { // 80 B: what the hit test reads
     uint32_t material;
 };
 static_assert(sizeof(DevPrim) == 80, "DevPrim must be 80 bytes");
-// One step of the wave-uniform walk used for small scenes: the tree in depth-first pre-order, boxes and
-// primitives inline.  kind 0 = node (d[0..5] = box, aux = index of the item after this subtree);
-// kind 1 + PT_PRIM_* = primitive (d = DevPrim::d, aux = primitive index).
-struct WalkItem {
-    uint32_t kind;
-    uint32_t aux;
-    double d[9];
-};
-static_assert(sizeof(WalkItem) == 80, "WalkItem must be 80 bytes");
-#define PT_WALK_MAX_ITEMS 192
+// The wave-uniform walk used for small scenes reads the tree as a byte stream of records in depth-first pre-order
+// (what the reference's recursion visits, bvh.rs:107-121), each {u32 kind, u32 aux, f64 payload[]}:
+//   PT_WK_NODE      payload box min xyz, max xyz (6)       aux = byte offset of the first record after the subtree
+//   PT_WK_RECT_XY/XZ/YZ  payload k, a_lo, a_hi, b_lo, b_hi (5)   aux = primitive index
+//   PT_WK_BOX6      payload box min xyz, max xyz (6)       aux = index of the first of the six rectangles of an AABox
+//                   (geometry.rs:391-446 builds the sides from exactly these six numbers; the upload verifies it)
+//   PT_WK_SPHERE    payload center, radius (4)             aux = primitive index
+//   PT_WK_TRIANGLE  payload point1, edge1, edge2 (9)       aux = primitive index
+enum { PT_WK_NODE = 0, PT_WK_RECT_XY = 1, PT_WK_RECT_XZ = 2, PT_WK_RECT_YZ = 3, PT_WK_BOX6 = 4, PT_WK_SPHERE = 5, PT_WK_TRIANGLE = 6 };
+#define PT_WK_NODE_BYTES 56u
+#define PT_WK_RECT_BYTES 48u
+#define PT_WK_BOX6_BYTES 56u
+#define PT_WK_SPHERE_BYTES 40u
+#define PT_WK_TRIANGLE_BYTES 80u
+#define PT_WALK_MAX_ITEMS 192 /* nodes + primitives: the stream stays within the scalar cache */
+#define PT_WALK_PLANES_IN_RANGE 1u /* walk_flags: see walk_division_is_proven */
 // Everything shade needs about the primitive it hit, in ONE 80-byte record (one dependent fetch instead of the
 // chain primitive -> material -> texture): the geometry the normal comes from, the material, and the colour
 // when the material's texture is a solid one.
@@ -170,8 +176,8 @@ struct DevScene {
     uint32_t lds_nodes; // nodes [0, lds_nodes) are staged in LDS by the trace kernel
     uint32_t lds_prims; // primitives [0, lds_prims) likewise (all of them for small scenes)
     uint32_t stack_depth;
-    const WalkItem* walk; // non-null when the scene is small enough for the wave-uniform walk
-    uint32_t n_walk;
+    const unsigned char* walk; // non-null when the scene is small enough for the wave-uniform walk
+    uint32_t walk_bytes;
     uint32_t walk_flags; // PT_WALK_*
     uint32_t has_procedural; // any checker / marble texture
     const ShadePrim* shade_prims;
@@ -398,7 +404,8 @@ __device__ __forceinline__ double div_given_reciprocal(double n, double d, doubl
     return div_proven(n, d, y);
 }
 // The conditions of div_proven for every rectangle quotient (k - o_c) / d_c of a ray, established once per ray:
-//   scene (checked at upload, PT_WALK_PLANES_IN_RANGE): every rectangle plane k is 0 or 2^-800 <= |k| <= 2^400;
+//   scene (checked at upload, PT_WALK_PLANES_IN_RANGE): every rectangle plane k is 0 or 2^-800 <= |k| <= 2^400, and every
+//          node box is finite with min <= max (for walk_aabb_miss_finite below);
 //   ray: each origin component is 0 or in that same range, each reciprocal 1/d_c is in [2^-150, 2^150].
 // Then n = k - o_c is +-0 or 2^-853 <= |n| <= 2^401 (a nonzero difference of two such numbers is at least half an ulp of
 // the larger), q0 = n*y is 0 or in [2^-1003, 2^551]: normal, and the residual, a multiple of ulp(q0)*ulp(d) >= 2^-957,
@@ -410,24 +417,58 @@ __device__ __forceinline__ bool walk_division_is_proven(V3 o, V3 inv) {
                     coordinate_in_range(o.x) && coordinate_in_range(o.y) && coordinate_in_range(o.z);
     return lanes_where(ok) == lanes_where(true);
 }
-#define PT_WALK_PLANES_IN_RANGE 1u
 
-// lanes that do NOT hit the rectangle (geometry.rs:210-221 and the XZ / YZ twins); t for all lanes
-template <bool PROVEN>
-__device__ __forceinline__ LaneMask walk_rect_out(const double* g, double on, double dn, double inv_dn, double oa, double da,
-                                                  double ob, double db, double t_min, double t_max, double& t_out) {
-#ifdef PT_NO_FAST_DIV
-    double t = (g[0] - on) / dn;
-#else
-    double t = PROVEN ? div_proven(g[0] - on, dn, inv_dn) : div_ieee_unspeculated(g[0] - on, dn);
-#endif
-    LaneMask out = lanes_where(t < t_min) | lanes_where(t > t_max);
-    double a = oa + t * da;
-    double b = ob + t * db;
-    out |= lanes_where(a < g[1]) | lanes_where(a > g[2]) | lanes_where(b < g[3]) | lanes_where(b > g[4]);
-    t_out = t;
-    return out;
+// The box test when no product can be NaN (finite nonzero reciprocals, finite box with min <= max -- both established
+// before this variant is chosen): (min - o)*inv and (max - o)*inv are then ordered by the sign of inv, so the swap of
+// bvh.rs:25-27 is min/max of the pair; and since the interval only ever shrinks, "empty after some axis" (the early
+// returns of bvh.rs:30-32) is "empty after the last axis": one comparison instead of three.
+__device__ __forceinline__ LaneMask walk_aabb_miss_finite(const double* b, V3 o, V3 inv, double t_min, double t_max) {
+    double t0 = (b[0] - o.x) * inv.x, t1 = (b[3] - o.x) * inv.x;
+    t_min = fmax(fmin(t0, t1), t_min);
+    t_max = fmin(fmax(t0, t1), t_max);
+    t0 = (b[1] - o.y) * inv.y; t1 = (b[4] - o.y) * inv.y;
+    t_min = fmax(fmin(t0, t1), t_min);
+    t_max = fmin(fmax(t0, t1), t_max);
+    t0 = (b[2] - o.z) * inv.z; t1 = (b[5] - o.z) * inv.z;
+    t_min = fmax(fmin(t0, t1), t_min);
+    t_max = fmin(fmax(t0, t1), t_max);
+    return lanes_where(t_max <= t_min);
 }
+
+// One rectangle (geometry.rs:210-221 and the XZ / YZ twins) for the lanes of `act`: plane k on axis n, extent
+// [a_lo, a_hi] x [b_lo, b_hi] on the other two.  The six rejection tests of the reference narrow EXEC one v_cmpx at a
+// time (a lane survives "not (t < t_min)" etc., so NaNs fall as in the reference), the survivors take the hit with
+// three moves, and EXEC is put back: no mask arithmetic on the scalar unit, no selects.
+// The wave runs the walk with all 64 lanes enabled, so "back" is all ones.
+template <bool PROVEN>
+__device__ __forceinline__ void walk_rect(LaneMask act, double k, double a_lo, double a_hi, double b_lo, double b_hi, double on,
+                                          double dn, double inv_dn, double oa, double da, double ob, double db, double t_min,
+                                          uint32_t prim, double& best_t, int32_t& best_prim) {
+    const double n = k - on;
+#ifdef PT_NO_FAST_DIV
+    const double t = n / dn;
+#else
+    const double t = PROVEN ? div_proven(n, dn, inv_dn) : div_ieee_unspeculated(n, dn);
+#endif
+    const double a = oa + t * da;
+    const double b = ob + t * db;
+    asm volatile(
+        "s_mov_b64 exec, %[act]\n\t"
+        "v_cmpx_nlt_f64 vcc, %[t], %[tmin]\n\t"
+        "v_cmpx_ngt_f64 vcc, %[t], %[best]\n\t"
+        "v_cmpx_nlt_f64 vcc, %[a], %[alo]\n\t"
+        "v_cmpx_ngt_f64 vcc, %[a], %[ahi]\n\t"
+        "v_cmpx_nlt_f64 vcc, %[b], %[blo]\n\t"
+        "v_cmpx_ngt_f64 vcc, %[b], %[bhi]\n\t"
+        "v_mov_b64 %[best], %[t]\n\t"
+        "v_mov_b32 %[bp], %[prim]\n\t"
+        "s_mov_b64 exec, -1"
+        : [best] "+v"(best_t), [bp] "+v"(best_prim)
+        : [act] "s"(act), [t] "v"(t), [a] "v"(a), [b] "v"(b), [tmin] "s"(t_min), [alo] "s"(a_lo), [ahi] "s"(a_hi), [blo] "s"(b_lo),
+          [bhi] "s"(b_hi), [prim] "s"(prim)
+        : "vcc");
+}
+
 __device__ __forceinline__ LaneMask walk_sphere(const double* g, LaneMask act, V3 o, V3 d, double t_min, double t_max, double& t_out) {
     V3 oc = o - v3(g[0], g[1], g[2]); // geometry.rs:132-148
     double a = len_squared(d);
@@ -474,51 +515,72 @@ __device__ __forceinline__ LaneMask walk_triangle(const double* g, LaneMask act,
     return hit;
 }
 
+// PROVEN: the conditions of walk_division_is_proven hold for this wave's rays and this scene.
 template <bool PROVEN>
-__device__ __forceinline__ void traverse_walk_loop(const WalkItem* __restrict__ walk, uint32_t n_walk, bool lane_live, V3 o, V3 d,
-                                                   V3 inv, double t_min, double& best_t, int32_t& best_prim) {
-    uint32_t skip_until = lane_live ? 0u : 0xFFFFFFFFu;
-    uint32_t i = 0;
-    while (i < n_walk) {
-        i = __builtin_amdgcn_readfirstlane(i);
-        const WalkItem it = walk[i]; // one 80-byte scalar fetch per step
-        const uint32_t kind = it.kind;
-        const uint32_t aux = it.aux;
-        const LaneMask act = lanes_where(skip_until <= i);
-        if (kind == 0u) {
-            const LaneMask miss = walk_aabb_miss(it.d, o, inv, t_min, best_t);
-            if (lane_in(act & miss)) skip_until = aux;
-            i = (act & ~miss) ? i + 1u : aux;
-        } else {
-            if (act) {
-                double t = 0.0;
-                LaneMask h;
-                switch (kind - 1u) { // wave-uniform: a scalar branch
-                    case PT_PRIM_SPHERE: h = walk_sphere(it.d, act, o, d, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_XY: h = act & ~walk_rect_out<PROVEN>(it.d, o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_XZ: h = act & ~walk_rect_out<PROVEN>(it.d, o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, best_t, t); break;
-                    case PT_PRIM_RECT_YZ: h = act & ~walk_rect_out<PROVEN>(it.d, o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, best_t, t); break;
-                    default: h = walk_triangle(it.d, act, o, d, t_min, best_t, t); break;
-                }
-                if (lane_in(h)) {
-                    best_t = t;
-                    best_prim = (int32_t)aux;
-                }
-            }
-            i = i + 1u;
+__device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restrict__ walk, uint32_t walk_bytes, bool lane_live, V3 o,
+                                                   V3 d, V3 inv, double t_min, double& best_t, int32_t& best_prim) {
+    uint32_t skip_until = lane_live ? 0u : 0xFFFFFFFFu; // byte offset from which this lane takes part again
+    uint32_t off = 0;
+    while (off < walk_bytes) {
+        off = __builtin_amdgcn_readfirstlane(off);
+        const uint32_t* hdr = reinterpret_cast<const uint32_t*>(walk + off); // scalar fetches: the record feeds the VALU from SGPRs
+        const double* g = reinterpret_cast<const double*>(walk + off + 8u);
+        const uint32_t kind = hdr[0];
+        const uint32_t aux = hdr[1];
+        const LaneMask act = lanes_where(skip_until <= off);
+        if (kind == PT_WK_NODE) {
+            const LaneMask miss = PROVEN ? walk_aabb_miss_finite(g, o, inv, t_min, best_t) : walk_aabb_miss(g, o, inv, t_min, best_t);
+            if (lane_in(act & miss)) skip_until = aux; // bvh.rs:108-110: this lane sits the subtree out
+            off = (act & ~miss) ? off + PT_WK_NODE_BYTES : aux;
+            continue;
         }
+        if (kind == PT_WK_BOX6) { // geometry.rs:70-83 over the six sides, in list order
+            if (act) {
+                const double x0 = g[0], y0 = g[1], z0 = g[2], x1 = g[3], y1 = g[4], z1 = g[5];
+                walk_rect<PROVEN>(act, z0, x0, x1, y0, y1, o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, aux, best_t, best_prim);
+                walk_rect<PROVEN>(act, z1, x0, x1, y0, y1, o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, aux + 1u, best_t, best_prim);
+                walk_rect<PROVEN>(act, y0, x0, x1, z0, z1, o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, aux + 2u, best_t, best_prim);
+                walk_rect<PROVEN>(act, y1, x0, x1, z0, z1, o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, aux + 3u, best_t, best_prim);
+                walk_rect<PROVEN>(act, x0, y0, y1, z0, z1, o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, aux + 4u, best_t, best_prim);
+                walk_rect<PROVEN>(act, x1, y0, y1, z0, z1, o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, aux + 5u, best_t, best_prim);
+            }
+            off += PT_WK_BOX6_BYTES;
+            continue;
+        }
+        if (kind <= PT_WK_RECT_YZ) {
+            if (act) {
+                if (kind == PT_WK_RECT_XY)
+                    walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, aux, best_t, best_prim);
+                else if (kind == PT_WK_RECT_XZ)
+                    walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, aux, best_t, best_prim);
+                else
+                    walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, aux, best_t, best_prim);
+            }
+            off += PT_WK_RECT_BYTES;
+            continue;
+        }
+        if (act) {
+            double t = 0.0;
+            const LaneMask h = (kind == PT_WK_SPHERE) ? walk_sphere(g, act, o, d, t_min, best_t, t) : walk_triangle(g, act, o, d, t_min, best_t, t);
+            if (lane_in(h)) {
+                best_t = t;
+                best_prim = (int32_t)aux;
+            }
+        }
+        off += (kind == PT_WK_SPHERE) ? PT_WK_SPHERE_BYTES : PT_WK_TRIANGLE_BYTES;
     }
 }
 
-__device__ __forceinline__ void traverse_walk(const WalkItem* __restrict__ walk, uint32_t n_walk, uint32_t walk_flags, bool lane_live,
-                                              V3 o, V3 d, double t_min, double t_max, double& best_t, int32_t& best_prim) {
+__device__ __forceinline__ void traverse_walk(const unsigned char* __restrict__ walk, uint32_t walk_bytes, uint32_t walk_flags,
+                                              bool lane_live, V3 o, V3 d, double t_min, double t_max, double& best_t,
+                                              int32_t& best_prim) {
     V3 inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
     best_t = t_max;
     best_prim = -1;
     if ((walk_flags & PT_WALK_PLANES_IN_RANGE) && walk_division_is_proven(o, inv))
-        traverse_walk_loop<true>(walk, n_walk, lane_live, o, d, inv, t_min, best_t, best_prim);
+        traverse_walk_loop<true>(walk, walk_bytes, lane_live, o, d, inv, t_min, best_t, best_prim);
     else
-        traverse_walk_loop<false>(walk, n_walk, lane_live, o, d, inv, t_min, best_t, best_prim);
+        traverse_walk_loop<false>(walk, walk_bytes, lane_live, o, d, inv, t_min, best_t, best_prim);
 }
 
 // Outward normal of primitive `prim` at point p: geometry.rs:151 (sphere), :227/:290/:353 (rectangles),

@@ -466,48 +466,80 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
         }
     }
 
-    // small scenes: the pre-order item list of the wave-uniform walk (pt_device.h traverse_walk)
-    std::vector<WalkItem> walk;
+    // small scenes: the pre-order record stream of the wave-uniform walk (pt_device.h traverse_walk)
+    std::vector<uint64_t> walk; // 8-byte words; a record = {kind | aux << 32} + payload doubles
+    uint32_t walk_flags = PT_WALK_PLANES_IN_RANGE;
     if ((uint64_t)s->n_nodes + s->n_prims <= PT_WALK_MAX_ITEMS) {
-        // iterative pre-order: (ref, parent item to patch when the subtree ends)
+        auto put_header = [&](uint32_t kind, uint32_t aux_word) { walk.push_back((uint64_t)kind | ((uint64_t)aux_word << 32)); };
+        auto put = [&](double v) {
+            uint64_t bits;
+            std::memcpy(&bits, &v, 8);
+            walk.push_back(bits);
+        };
+        auto plane_ok = [](double k) { k = std::fabs(k); return k == 0.0 || (k >= 0x1p-800 && k <= 0x1p400); };
+        auto same = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0; };
+        // iterative pre-order: (ref, stage, word index of the node's header to patch when its subtree ends)
         struct Frame { uint32_t ref; int stage; uint32_t item; };
         std::vector<Frame> st;
         st.push_back({s->root, 0, 0});
         while (!st.empty()) {
             Frame& fr = st.back();
             if (fr.ref & PT_REF_LEAF) {
-                uint32_t first = fr.ref & PT_REF_INDEX_MASK, count = (fr.ref & PT_REF_GROUP6) ? 6u : 1u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    WalkItem it;
-                    std::memset(&it, 0, sizeof(it));
-                    it.kind = 1u + prims[first + k].type;
-                    it.aux = first + k;
-                    for (int q = 0; q < 9; ++q) it.d[q] = prims[first + k].d[q];
-                    walk.push_back(it);
+                const uint32_t first = fr.ref & PT_REF_INDEX_MASK, count = (fr.ref & PT_REF_GROUP6) ? 6u : 1u;
+                bool as_box = false;
+                if (count == 6u) {
+                    // the six sides of an AABox as built by geometry.rs:391-446: all from one (min, max) pair
+                    const DevPrim* r = &prims[first];
+                    const double x0 = r[4].d[0], x1 = r[5].d[0], y0 = r[2].d[0], y1 = r[3].d[0], z0 = r[0].d[0], z1 = r[1].d[0];
+                    as_box = r[0].type == PT_PRIM_RECT_XY && r[1].type == PT_PRIM_RECT_XY && r[2].type == PT_PRIM_RECT_XZ &&
+                             r[3].type == PT_PRIM_RECT_XZ && r[4].type == PT_PRIM_RECT_YZ && r[5].type == PT_PRIM_RECT_YZ;
+                    for (int k = 0; k < 2 && as_box; ++k) {
+                        as_box = same(r[k].d[1], x0) && same(r[k].d[2], x1) && same(r[k].d[3], y0) && same(r[k].d[4], y1) &&
+                                 same(r[2 + k].d[1], x0) && same(r[2 + k].d[2], x1) && same(r[2 + k].d[3], z0) && same(r[2 + k].d[4], z1) &&
+                                 same(r[4 + k].d[1], y0) && same(r[4 + k].d[2], y1) && same(r[4 + k].d[3], z0) && same(r[4 + k].d[4], z1);
+                    }
+                    if (as_box) {
+                        put_header(PT_WK_BOX6, first);
+                        for (double v : {x0, y0, z0, x1, y1, z1}) {
+                            put(v);
+                            if (!plane_ok(v)) walk_flags = 0;
+                        }
+                    }
+                }
+                for (uint32_t k = 0; k < count && !as_box; ++k) {
+                    const DevPrim& pr = prims[first + k];
+                    if (pr.type == PT_PRIM_SPHERE) {
+                        put_header(PT_WK_SPHERE, first + k);
+                        for (int q = 0; q < 4; ++q) put(pr.d[q]);
+                    } else if (pr.type == PT_PRIM_TRIANGLE) {
+                        put_header(PT_WK_TRIANGLE, first + k);
+                        for (int q = 0; q < 9; ++q) put(pr.d[q]);
+                    } else {
+                        put_header(PT_WK_RECT_XY + (pr.type - PT_PRIM_RECT_XY), first + k);
+                        for (int q = 0; q < 5; ++q) put(pr.d[q]);
+                        if (!plane_ok(pr.d[0])) walk_flags = 0;
+                    }
                 }
                 st.pop_back();
                 continue;
             }
             const PtNode& nd = s->nodes[fr.ref];
             if (fr.stage == 0) {
-                WalkItem it;
-                std::memset(&it, 0, sizeof(it));
-                it.kind = 0;
-                for (int q = 0; q < 3; ++q) {
-                    it.d[q] = nd.bmin[q];
-                    it.d[3 + q] = nd.bmax[q];
-                }
                 fr.item = (uint32_t)walk.size();
-                walk.push_back(it);
+                put_header(PT_WK_NODE, 0);
+                for (int q = 0; q < 3; ++q) put(nd.bmin[q]);
+                for (int q = 0; q < 3; ++q) put(nd.bmax[q]);
+                for (int q = 0; q < 3; ++q)
+                    if (!(std::isfinite(nd.bmin[q]) && std::isfinite(nd.bmax[q]) && nd.bmin[q] <= nd.bmax[q])) walk_flags = 0;
                 fr.stage = 1;
-                uint32_t child = nd.left;
+                const uint32_t child = nd.left;
                 st.push_back({child, 0, 0});
             } else if (fr.stage == 1) {
                 fr.stage = 2;
-                uint32_t child = nd.right;
+                const uint32_t child = nd.right;
                 st.push_back({child, 0, 0});
             } else {
-                walk[fr.item].aux = (uint32_t)walk.size();  // first item after this subtree
+                walk[fr.item] |= (uint64_t)(walk.size() * 8u) << 32;  // byte offset of the first record after this subtree
                 st.pop_back();
             }
         }
@@ -519,8 +551,8 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     PT_HIP(ctx, ensure_buf(ctx->d_shade, shade_prims.size() * sizeof(ShadePrim)));
     PT_HIP(ctx, hipMemcpy(ctx->d_shade.p, shade_prims.data(), shade_prims.size() * sizeof(ShadePrim), hipMemcpyHostToDevice));
     if (!walk.empty()) {
-        PT_HIP(ctx, ensure_buf(ctx->d_walk, walk.size() * sizeof(WalkItem)));
-        PT_HIP(ctx, hipMemcpy(ctx->d_walk.p, walk.data(), walk.size() * sizeof(WalkItem), hipMemcpyHostToDevice));
+        PT_HIP(ctx, ensure_buf(ctx->d_walk, walk.size() * sizeof(uint64_t)));
+        PT_HIP(ctx, hipMemcpy(ctx->d_walk.p, walk.data(), walk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
     PT_HIP(ctx, ensure_buf(ctx->d_nodes, nodes.size() * sizeof(DevNode)));
     PT_HIP(ctx, ensure_buf(ctx->d_prims, prims.size() * sizeof(DevPrim)));
@@ -550,18 +582,9 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.n_textures = s->n_textures;
     sc.root = 0;  // the root is first in breadth-first order
     sc.stack_depth = tc.max_depth;
-    sc.walk = walk.empty() ? nullptr : (const WalkItem*)ctx->d_walk.p;
-    sc.n_walk = (uint32_t)walk.size();
-    // the lockstep walk forms rectangle quotients from the ray's reciprocal when every plane coordinate is 0 or of
-    // ordinary magnitude (pt_device.h walk_division_is_proven); any other scene keeps the IEEE division
-    sc.walk_flags = PT_WALK_PLANES_IN_RANGE;
-    for (const WalkItem& it : walk) {
-        const uint32_t type = it.kind - 1u;
-        if (it.kind != 0u && (type == PT_PRIM_RECT_XY || type == PT_PRIM_RECT_XZ || type == PT_PRIM_RECT_YZ)) {
-            const double k = std::fabs(it.d[0]);
-            if (!(k == 0.0 || (k >= 0x1p-800 && k <= 0x1p400))) sc.walk_flags = 0;
-        }
-    }
+    sc.walk = walk.empty() ? nullptr : (const unsigned char*)ctx->d_walk.p;
+    sc.walk_bytes = (uint32_t)(walk.size() * sizeof(uint64_t));
+    sc.walk_flags = walk_flags;
     sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
     sc.has_procedural = 0;
     for (uint32_t i = 0; i < s->n_textures; ++i)

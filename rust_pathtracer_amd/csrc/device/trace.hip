@@ -45,7 +45,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, RayStream 
 }
 
 // Small scenes: the wave-uniform walk (pt_device.h traverse_walk).  No LDS, no per-lane stack.
-__global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __restrict__ walk, uint32_t n_walk, uint32_t walk_flags, RayStream rays,
+__global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const unsigned char* __restrict__ walk, uint32_t walk_bytes, uint32_t walk_flags, RayStream rays,
                                                               const uint32_t* __restrict__ counts, uint32_t n_waves,
                                                               double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
     const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __
         }
         double t;
         int32_t prim;
-        traverse_walk(walk, n_walk, walk_flags, live, v3(a.x, a.y, b.x), v3(b.y, c.x, c.y), 0.001, __builtin_huge_val(), t, prim);
+        traverse_walk(walk, walk_bytes, walk_flags, live, v3(a.x, a.y, b.x), v3(b.y, c.x, c.y), 0.001, __builtin_huge_val(), t, prim);
         if (live) {
             hit_t[i] = t;
             hit_prim[i] = prim;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const WalkItem* __
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io) {
     const RayStream& in = wf.rays[io.in];
     if (sc.walk) {
-        hipLaunchKernelGGL(trace_walk_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.n_walk, sc.walk_flags, in, io.counts_in, wf.n_waves,
+        hipLaunchKernelGGL(trace_walk_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.walk_bytes, sc.walk_flags, in, io.counts_in, wf.n_waves,
                            wf.hit_t, wf.hit_prim);
         return;
     }
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_walk_kernel(DevScene sc,
         }
         double t;
         int32_t prim;
-        traverse_walk(sc.walk, sc.n_walk, sc.walk_flags, live, o, d, t_min, t_max, t, prim);
+        traverse_walk(sc.walk, sc.walk_bytes, sc.walk_flags, live, o, d, t_min, t_max, t, prim);
         if (live) write_hit_record(sc, o, d, t, prim, out + i);
     }
 }
