@@ -523,6 +523,9 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
     uint32_t off = 0;
     while (off < walk_bytes) {
         off = __builtin_amdgcn_readfirstlane(off);
+        // one definition point per iteration for the per-lane state: keeps each in a single register across the
+        // dispatch below instead of a web of copies at every join
+        asm volatile("" : "+v"(best_t), "+v"(best_prim), "+v"(skip_until));
         const uint32_t* hdr = reinterpret_cast<const uint32_t*>(walk + off); // scalar fetches: the record feeds the VALU from SGPRs
         const double* g = reinterpret_cast<const double*>(walk + off + 8u);
         const uint32_t kind = hdr[0];
@@ -532,9 +535,7 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
             const LaneMask miss = PROVEN ? walk_aabb_miss_finite(g, o, inv, t_min, best_t) : walk_aabb_miss(g, o, inv, t_min, best_t);
             if (lane_in(act & miss)) skip_until = aux; // bvh.rs:108-110: this lane sits the subtree out
             off = (act & ~miss) ? off + PT_WK_NODE_BYTES : aux;
-            continue;
-        }
-        if (kind == PT_WK_BOX6) { // geometry.rs:70-83 over the six sides, in list order
+        } else if (kind == PT_WK_BOX6) { // geometry.rs:70-83 over the six sides, in list order
             if (act) {
                 const double x0 = g[0], y0 = g[1], z0 = g[2], x1 = g[3], y1 = g[4], z1 = g[5];
                 walk_rect<PROVEN>(act, z0, x0, x1, y0, y1, o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, aux, best_t, best_prim);
@@ -545,29 +546,26 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
                 walk_rect<PROVEN>(act, x1, y0, y1, z0, z1, o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, aux + 5u, best_t, best_prim);
             }
             off += PT_WK_BOX6_BYTES;
-            continue;
-        }
-        if (kind <= PT_WK_RECT_YZ) {
-            if (act) {
-                if (kind == PT_WK_RECT_XY)
-                    walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, aux, best_t, best_prim);
-                else if (kind == PT_WK_RECT_XZ)
-                    walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, aux, best_t, best_prim);
-                else
-                    walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, aux, best_t, best_prim);
-            }
+        } else if (kind == PT_WK_RECT_XY) {
+            if (act) walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.z, d.z, inv.z, o.x, d.x, o.y, d.y, t_min, aux, best_t, best_prim);
             off += PT_WK_RECT_BYTES;
-            continue;
-        }
-        if (act) {
-            double t = 0.0;
-            const LaneMask h = (kind == PT_WK_SPHERE) ? walk_sphere(g, act, o, d, t_min, best_t, t) : walk_triangle(g, act, o, d, t_min, best_t, t);
-            if (lane_in(h)) {
-                best_t = t;
-                best_prim = (int32_t)aux;
+        } else if (kind == PT_WK_RECT_XZ) {
+            if (act) walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.y, d.y, inv.y, o.x, d.x, o.z, d.z, t_min, aux, best_t, best_prim);
+            off += PT_WK_RECT_BYTES;
+        } else if (kind == PT_WK_RECT_YZ) {
+            if (act) walk_rect<PROVEN>(act, g[0], g[1], g[2], g[3], g[4], o.x, d.x, inv.x, o.y, d.y, o.z, d.z, t_min, aux, best_t, best_prim);
+            off += PT_WK_RECT_BYTES;
+        } else {
+            if (act) {
+                double t = 0.0;
+                const LaneMask h = (kind == PT_WK_SPHERE) ? walk_sphere(g, act, o, d, t_min, best_t, t) : walk_triangle(g, act, o, d, t_min, best_t, t);
+                if (lane_in(h)) {
+                    best_t = t;
+                    best_prim = (int32_t)aux;
+                }
             }
+            off += (kind == PT_WK_SPHERE) ? PT_WK_SPHERE_BYTES : PT_WK_TRIANGLE_BYTES;
         }
-        off += (kind == PT_WK_SPHERE) ? PT_WK_SPHERE_BYTES : PT_WK_TRIANGLE_BYTES;
     }
 }
 
