@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_${1:-r01}
 mkdir -p $OUT
-BENCH="python3 bench.py --spp 16 --steps 1 --warmup 0 --no-cpu-baseline"
+BENCH="python3 bench.py --spp 16 --steps 1 --warmup 0 --no-cpu-baseline --lanes 1"
 run_pass() {
   name=$1; shift
   timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $BENCH > $OUT/$name.log 2>&1

@@ -30,7 +30,7 @@ __device__ __forceinline__ double len_squared(V3 a) { return a.x * a.x + a.y * a
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {                                                      // :91-97
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ V3 unit_vector(V3 a) { return a / sqrt(len_squared(a)); }                   // :99-101
+__device__ __forceinline__ V3 unit_vector_ieee(V3 a) { return a / sqrt(len_squared(a)); }              // :99-101
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0 * dot(v, n)) * n; }                // :114-116
 __device__ __forceinline__ V3 refract(V3 v, V3 n, double etai_over_etat) {                              // :118-127
     double cos_theta = fmin(dot(neg(v), n), 1.0);
@@ -112,6 +112,39 @@ __device__ __forceinline__ V3 random_in_unitdisk_xy(SampleRng& rng) { // vec3.rs
         double y = rng.range(-1.0, 1.0);
         p = v3(x, y, 0.0);
         if (len_squared(p) < 1.0) break;
+    }
+    return p;
+}
+
+// One draw as SampleRng::range(-1.0, 1.0) returns it, from the two words of its 64-bit half: with m = bits >> 11,
+// -1 + 2 * (m * 2^-53) is a single rounding of m * 2^-52 - 1, which the FMA below performs (m itself is exact).
+__device__ __forceinline__ double draw_pm1(uint32_t lo, uint32_t hi) {
+    const uint32_t m_lo = __builtin_amdgcn_alignbit(hi, lo, 11);
+    const uint32_t m_hi = hi >> 11;
+    const double m = __builtin_fma((double)m_hi, 0x1p32, (double)m_lo);
+    return __builtin_fma(m, 0x1p-52, -1.0);
+}
+// vec3.rs:41-49 on stream (pixel, sample, stream) of the key, from its first draw: the same candidates in the same
+// order as random_in_unitsphere(SampleRng&), evaluated two tries at a time -- tries 2m and 2m+1 are draws 6m..6m+5,
+// exactly blocks 3m..3m+2 -- and as one wave: the loop runs until every calling lane has accepted (a lane that has
+// keeps its point), so there is no divergent loop and no per-draw block cache.  77 % of lanes are done after one
+// round; a 64-lane wave needs ~3 rounds against ~6.5 single-try iterations.
+__device__ __forceinline__ V3 random_in_unitsphere_stream(uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1) {
+    V3 p = v3(0.0, 0.0, 0.0);
+    bool done = false;
+    for (uint32_t pair = 0; pair < PT_REJECTION_CAP / 2; ++pair) {
+        uint32_t b0[4], b1[4], b2[4];
+        philox4x32_10(pixel, sample, stream, 3u * pair, k0, k1, b0);
+        philox4x32_10(pixel, sample, stream, 3u * pair + 1u, k0, k1, b1);
+        philox4x32_10(pixel, sample, stream, 3u * pair + 2u, k0, k1, b2);
+        const V3 c0 = v3(draw_pm1(b0[0], b0[1]), draw_pm1(b0[2], b0[3]), draw_pm1(b1[0], b1[1]));
+        const V3 c1 = v3(draw_pm1(b1[2], b1[3]), draw_pm1(b2[0], b2[1]), draw_pm1(b2[2], b2[3]));
+        const bool a0 = len_squared(c0) < 1.0, a1 = len_squared(c1) < 1.0;
+        if (!done) {
+            p = a0 ? c0 : c1; // both rejected: the later candidate stands, as when the reference's loop is cut off
+            done = a0 | a1;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     }
     return p;
 }
@@ -418,6 +451,20 @@ __device__ __forceinline__ bool walk_division_is_proven(V3 o, V3 inv) {
     return lanes_where(ok) == lanes_where(true);
 }
 
+// vec3.rs:99-101, a / |a| component by component, with ONE division: y = 1 / |a|, then each quotient by div_proven.
+// Its conditions, voted by the wave: 2^-1000 <= |a| <= 2^200 (y is a normal number, no quotient underflows) and every
+// component at least 2^-800 in magnitude (exact residuals; |component / length| <= 1 rules out overflow).  Any lane
+// outside -- including an exactly zero component -- sends the wave through the three IEEE divisions.
+__device__ __forceinline__ V3 unit_vector(V3 a) {
+    const double len = sqrt(len_squared(a));
+    const double smallest = fmin(fmin(fabs(a.x), fabs(a.y)), fabs(a.z));
+    const LaneMask ok = lanes_where(smallest >= 0x1p-800) & lanes_where(len <= 0x1p200) & lanes_where(len >= 0x1p-1000);
+    if (__builtin_expect(ok != lanes_where(true), 0))
+        return v3(div_ieee_unspeculated(a.x, len), div_ieee_unspeculated(a.y, len), div_ieee_unspeculated(a.z, len));
+    const double y = 1.0 / len;
+    return v3(div_proven(a.x, len, y), div_proven(a.y, len, y), div_proven(a.z, len, y));
+}
+
 // The box test when no product can be NaN (finite nonzero reciprocals, finite box with min <= max -- both established
 // before this variant is chosen): (min - o)*inv and (max - o)*inv are then ordered by the sign of inv, so the swap of
 // bvh.rs:25-27 is min/max of the pair; and since the interval only ever shrinks, "empty after some axis" (the early
@@ -686,41 +733,44 @@ __device__ __forceinline__ double reflectance(double cosine, double refraction_i
     return r0 + (1.0 - r0) * (m * m4);
 }
 
-// Material::scatter for the hit (point p, unit-or-not normal n already flipped to oppose the ray).
-// Returns false when the path ends (no scatter).  attenuation is evaluated by the caller via texture_value.
-__device__ __forceinline__ bool scatter(uint32_t mat_type, double mat_param, V3 ray_d, V3 n, bool front_face, SampleRng& rng,
-                                        V3& out_d, bool& textured) {
-    switch (mat_type) {
-        case PT_MAT_LAMBERTIAN: { // material.rs:41-55
-            V3 dir = n + unit_vector(random_in_unitsphere(rng));
-            if (near_zero(dir)) dir = n;
-            out_d = dir;
-            textured = true;
-            return true;
+// Material::scatter for the hit (point p, unit-or-not normal n already flipped to oppose the ray), drawing from stream
+// (pixel, sample, stream) of the key (k0, k1).  Returns false when the path ends (no scatter).  attenuation is
+// evaluated by the caller via texture_value.  Lambertian and Metal share one instance of the unit-sphere sampler.
+__device__ __forceinline__ bool scatter(uint32_t mat_type, double mat_param, V3 ray_d, V3 n, bool front_face, uint32_t pixel,
+                                        uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1, V3& out_d, bool& textured) {
+    if (mat_type == PT_MAT_DIELECTRIC) { // material.rs:117-143
+        double refraction_ratio = front_face ? 1.0 / mat_param : mat_param;
+        V3 unit_direction = unit_vector(ray_d);
+        double cos_theta = fmin(dot(neg(unit_direction), n), 1.0);
+        double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+        bool reflects = (refraction_ratio * sin_theta > 1.0);
+        if (!reflects) {
+            uint32_t b[4];
+            philox4x32_10(pixel, sample, stream, 0u, k0, k1, b); // the stream's first draw (rng.gen::<f64>(), material.rs:132)
+            const uint64_t bits = ((uint64_t)b[1] << 32) | b[0];
+            reflects = reflectance(cos_theta, refraction_ratio) > (double)(bits >> 11) * (1.0 / 9007199254740992.0);
         }
-        case PT_MAT_METAL: { // material.rs:77-93
-            V3 reflected = reflect(unit_vector(ray_d), n);
-            if (dot(reflected, n) > 0.0) {
-                out_d = reflected + mat_param * random_in_unitsphere(rng);
-                textured = true;
-                return true;
-            }
-            return false;
-        }
-        case PT_MAT_DIELECTRIC: { // material.rs:117-143
-            double refraction_ratio = front_face ? 1.0 / mat_param : mat_param;
-            V3 unit_direction = unit_vector(ray_d);
-            double cos_theta = fmin(dot(neg(unit_direction), n), 1.0);
-            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-            bool reflects = (refraction_ratio * sin_theta > 1.0);
-            if (!reflects) reflects = reflectance(cos_theta, refraction_ratio) > rng.f64();
-            out_d = reflects ? reflect(unit_direction, n) : refract(unit_direction, n, refraction_ratio);
-            textured = false; // attenuation (1,1,1)
-            return true;
-        }
-        default: // DiffuseLight never scatters (material.rs:16-18)
-            return false;
+        out_d = reflects ? reflect(unit_direction, n) : refract(unit_direction, n, refraction_ratio);
+        textured = false; // attenuation (1,1,1)
+        return true;
     }
+    if (mat_type != PT_MAT_LAMBERTIAN && mat_type != PT_MAT_METAL) return false; // DiffuseLight never scatters (material.rs:16-18)
+    const bool metal = mat_type == PT_MAT_METAL;
+    V3 reflected = v3(0.0, 0.0, 0.0);
+    if (metal) { // material.rs:77-93
+        reflected = reflect(unit_vector(ray_d), n);
+        if (!(dot(reflected, n) > 0.0)) return false;
+    }
+    const V3 s = random_in_unitsphere_stream(pixel, sample, stream, k0, k1);
+    if (metal) {
+        out_d = reflected + mat_param * s;
+    } else { // material.rs:41-55
+        V3 dir = n + unit_vector(s);
+        if (near_zero(dir)) dir = n;
+        out_d = dir;
+    }
+    textured = true;
+    return true;
 }
 
 // ------------------------------------------------------------------ stream layouts

@@ -83,9 +83,8 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
                 } else if (!last_bounce) {
                     uint32_t slot = st.x / a.npix;
                     uint32_t pixel = st.x - slot * a.npix;
-                    SampleRng rng;
-                    rng.init(a.seed, pixel, a.sample_base + slot, a.bounce + 1u);
-                    alive = scatter(sp.mat_type, sp.param, d, nn, front, rng, next_d, textured);
+                    alive = scatter(sp.mat_type, sp.param, d, nn, front, pixel, a.sample_base + slot, a.bounce + 1u, (uint32_t)a.seed,
+                                    (uint32_t)(a.seed >> 32), next_d, textured);
                     next_o = p;
                 }
                 if (emits || (alive && textured)) {
