@@ -150,8 +150,9 @@ const char* pt_last_error(const PtContext* ctx);
  * "profile" (1 = time every kernel with HIP events and fill PtStats.ms_*; default 1),
  * "repack_every" / "repack_first" (re-deal surviving rays over the waves every N bounces from bounce F on;
  *   default 0 = never / 8),
- * "lanes" (2 = split every pass into two half-size sub-passes on two HIP streams, one pipeline step apart, so one's
- *   trace overlaps the other's shade; 1 = one stream; default 2),
+ * "lanes" (1..4: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
+ *   trace overlaps another's shade; default 2), "lane_sync" (1 = lanes advance in lock step through events; default 0
+ *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid; default 1),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 

@@ -134,6 +134,61 @@ def test_trace_edge_cases(gpu_ctx, oracle):
         assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
 
 
+def _box_world(tiny_plane):
+    """Rectangles and boxes only (the lockstep walk's fast paths), optionally with plane coordinates far outside the
+    range in which the walk forms quotients from reciprocals (pt_device.h walk_division_is_proven)."""
+    texs = [su._tex(0, color=(0.7, 0.7, 0.7))]
+    mats = [su._mat(0, 0)]
+    k = 1e-300 if tiny_plane else 0.25
+    objs = [
+        su._obj(1, 0, [-3, -3, k, 3, 3, k, 1.0]),            # XY rectangle at z = k
+        su._obj(2, 0, [-3, 0.0, -3, 3, 0.0, 3, 1.0]),        # XZ rectangle in the plane y = 0
+        su._obj(3, 0, [-2.0, -3, -3, -2.0, 3, 3, -1.0]),     # YZ rectangle at x = -2
+        su._obj(4, 0, [0.5, 0.5, 0.5, 2.0, 2.5, 1.5]),       # AABox
+        su._obj(4, 0, [-1.5, -2.5, (1e-290 if tiny_plane else -2.0), -0.5, -1.0, -0.5]),
+        su._obj(0, 0, [1.0, -1.5, 0.0, 0.8]),
+    ]
+    ps = su.pt.world_create([o[0] for o in objs], [m[0] for m in mats], [t[0] for t in texs], bvh_seed=3)
+    os_ = su.orc.OracleScene.custom([o[1] for o in objs], [m[1] for m in mats], [t[1] for t in texs], [], [], bvh_seed=3)
+    return ps, os_
+
+
+@pytest.mark.parametrize("tiny_plane", [False, True])
+def test_trace_extreme_magnitudes(gpu_ctx, oracle, tiny_plane):
+    """Rays whose coordinates leave the range in which the walk's shortcuts are proven (reciprocal quotients, NaN-free
+    box test) must come out exactly like ordinary ones: whole waves of them, and single ones salted into ordinary waves."""
+    s, o = _box_world(tiny_plane)
+    gpu_ctx.upload(s)
+    rng = np.random.default_rng(11)
+    n = 64 * 400
+    ro = rng.uniform(-4, 4, (n, 3))
+    rd = rng.uniform(-3, 3, (n, 3)) - ro * 0.5
+    odd_o = np.array([0.0, -0.0, 5e-324, 1e-300, -1e-310, 2.0 ** -801, 2.0 ** -799, 1e200, -1e300, 2.0 ** 401, 0.25, -2.0, 0.5, 1.5])
+    odd_d = np.array([0.0, -0.0, 5e-324, 1e-300, -1e-200, 2.0 ** -151, 2.0 ** -149, 2.0 ** 149, 2.0 ** 151, 1e200, -1e300, np.inf, 1.0, -1.0])
+    # first quarter: every ray has one odd coordinate; second quarter: one ray in ~40; rest: ordinary
+    q = n // 4
+    rows = np.arange(q)
+    ro[rows, rng.integers(0, 3, q)] = rng.choice(odd_o, q)
+    rows = np.arange(q) + q
+    rd[rows[: q // 2], rng.integers(0, 3, q // 2)] = rng.choice(odd_d, q // 2)
+    ro[rows[q // 2 :], rng.integers(0, 3, q - q // 2)] = rng.choice(odd_o[:9], q - q // 2)
+    salt = rng.random(n) < 0.025
+    salt[: 2 * q] = False
+    ro[salt, 0] = rng.choice(odd_o, salt.sum())
+    rd[salt, 1] = rng.choice(odd_d, salt.sum())
+    # rays that start exactly on a rectangle's plane (the common n = +0 case) and axis-parallel ones
+    ro[2 * q : 2 * q + 2000, 1] = 0.0
+    rd[2 * q + 2000 : 2 * q + 3000, 2] = 0.0
+    with np.errstate(all="ignore"):
+        prim, t, normal, front = o.trace(ro, rd)
+    assert (prim >= 0).mean() > 0.2
+    assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
+    for t_min, t_max in [(0.0, np.inf), (-1.0, 7.0)]:
+        with np.errstate(all="ignore"):
+            prim, t, normal, front = o.trace(ro[: 2 * q], rd[: 2 * q], t_min, t_max)
+        assert_hits_equal(gpu_ctx.trace_batch(ro[: 2 * q], rd[: 2 * q], t_min, t_max), prim, t, normal, front)
+
+
 # ---------------------------------------------------------------- textures (libm differs: tolerance, not bits)
 def test_texture_values_match_oracle(gpu_ctx, pt, oracle):
     s = pt.Scene("TwoSpheres").set_seeds(1, 1, 9).build()
