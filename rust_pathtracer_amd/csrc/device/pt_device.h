@@ -124,27 +124,76 @@ __device__ __forceinline__ double draw_pm1(uint32_t lo, uint32_t hi) {
     const double m = __builtin_fma((double)m_hi, 0x1p32, (double)m_lo);
     return __builtin_fma(m, 0x1p-52, -1.0);
 }
-// vec3.rs:41-49 on stream (pixel, sample, stream) of the key, from its first draw: the same candidates in the same
-// order as random_in_unitsphere(SampleRng&), evaluated two tries at a time -- tries 2m and 2m+1 are draws 6m..6m+5,
-// exactly blocks 3m..3m+2 -- and as one wave: the loop runs until every calling lane has accepted (a lane that has
-// keeps its point), so there is no divergent loop and no per-draw block cache.  77 % of lanes are done after one
-// round; a 64-lane wave needs ~3 rounds against ~6.5 single-try iterations.
-__device__ __forceinline__ V3 random_in_unitsphere_stream(uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1) {
+// vec3.rs:41-49 on stream (pixel, sample, stream) of the key, from its first draw: the same candidates in the same order
+// as random_in_unitsphere(SampleRng&) -- the first accepted one is returned -- but produced by the WAVE, not the lane.
+//   * Tries come in pairs: tries 2j and 2j+1 are draws 6j..6j+5, exactly Philox blocks 3j..3j+2.
+//   * Round one: every lane that needs a point evaluates its own pair 0; 77 % are done.
+//   * Later rounds: the m lanes still waiting publish (pixel, sample) in the wave's 64-slot exchange area; with S the
+//     power of two >= m, lane h evaluates pair base + h/S for the waiting lane of rank h%S, so each waiting lane has
+//     64/S consecutive pairs tried at once; it then takes the candidate of its first successful helper (lane mask ->
+//     strided bit scan -> six ds_bpermute).  A lone-lane tail of ~4 more rounds becomes one.
+//   * If more than 32 lanes wait there is nothing to share and every waiting lane evaluates its own next pair.
+// The cut-off of the reference's (endless) loop after PT_REJECTION_CAP tries keeps its meaning: the candidate of the last
+// try stands.  Must be called by all 64 lanes of the wave together (`need` says which lanes want a point);
+// `exchange` = this wave's 64 uint2 of LDS.
+__device__ __forceinline__ void unitsphere_pair(uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t pair, uint32_t k0, uint32_t k1,
+                                                V3& cand, bool& accepted) {
+    uint32_t b0[4], b1[4], b2[4];
+    philox4x32_10(pixel, sample, stream, 3u * pair, k0, k1, b0);
+    philox4x32_10(pixel, sample, stream, 3u * pair + 1u, k0, k1, b1);
+    philox4x32_10(pixel, sample, stream, 3u * pair + 2u, k0, k1, b2);
+    const V3 c0 = v3(draw_pm1(b0[0], b0[1]), draw_pm1(b0[2], b0[3]), draw_pm1(b1[0], b1[1]));
+    const V3 c1 = v3(draw_pm1(b1[2], b1[3]), draw_pm1(b2[0], b2[1]), draw_pm1(b2[2], b2[3]));
+    const bool a0 = len_squared(c0) < 1.0, a1 = len_squared(c1) < 1.0;
+    cand = a0 ? c0 : c1; // both rejected: the later candidate
+    accepted = a0 | a1;
+}
+__device__ __forceinline__ double lane_fetch(double v, uint32_t lane_byte_address) {
+    const int lo = __builtin_amdgcn_ds_bpermute((int)lane_byte_address, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute((int)lane_byte_address, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ V3 random_in_unitsphere_wave(bool need, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t k0,
+                                                        uint32_t k1, uint2* exchange) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     V3 p = v3(0.0, 0.0, 0.0);
-    bool done = false;
-    for (uint32_t pair = 0; pair < PT_REJECTION_CAP / 2; ++pair) {
-        uint32_t b0[4], b1[4], b2[4];
-        philox4x32_10(pixel, sample, stream, 3u * pair, k0, k1, b0);
-        philox4x32_10(pixel, sample, stream, 3u * pair + 1u, k0, k1, b1);
-        philox4x32_10(pixel, sample, stream, 3u * pair + 2u, k0, k1, b2);
-        const V3 c0 = v3(draw_pm1(b0[0], b0[1]), draw_pm1(b0[2], b0[3]), draw_pm1(b1[0], b1[1]));
-        const V3 c1 = v3(draw_pm1(b1[2], b1[3]), draw_pm1(b2[0], b2[1]), draw_pm1(b2[2], b2[3]));
-        const bool a0 = len_squared(c0) < 1.0, a1 = len_squared(c1) < 1.0;
-        if (!done) {
-            p = a0 ? c0 : c1; // both rejected: the later candidate stands, as when the reference's loop is cut off
-            done = a0 | a1;
+    unsigned long long waiting = __builtin_amdgcn_ballot_w64(need);
+    uint32_t base = 0; // pairs [0, base) have been tried by every waiting lane
+    const uint32_t cap_pairs = PT_REJECTION_CAP / 2;
+    while (waiting != 0ull && base < cap_pairs) {
+        const uint32_t m = (uint32_t)__builtin_popcountll(waiting);
+        const bool mine_waits = __builtin_amdgcn_inverse_ballot_w64(waiting);
+        if (m > 32u || base + 64u > cap_pairs) { // every waiting lane for itself
+            V3 cand;
+            bool acc;
+            unitsphere_pair(pixel, sample, stream, base, k0, k1, cand, acc);
+            if (mine_waits) p = cand;
+            waiting &= ~__builtin_amdgcn_ballot_w64(acc);
+            base += 1u;
+        } else {
+            const uint32_t shift = m <= 1u ? 0u : 32u - (uint32_t)__builtin_clz(m - 1u); // S = 1 << shift >= m, S <= 32
+            const uint32_t S = 1u << shift;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(waiting >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)waiting, 0u));
+            if (mine_waits) exchange[rank] = make_uint2(pixel, sample);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const uint32_t served = lane & (S - 1u);
+            const uint2 who = exchange[served];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            V3 cand;
+            bool acc;
+            unitsphere_pair(who.x, who.y, stream, base + (lane >> shift), k0, k1, cand, acc);
+            const unsigned long long ok = __builtin_amdgcn_ballot_w64(acc & (served < m));
+            // helpers of the lane of rank r sit at lanes r, r + S, r + 2S, ...: the lowest one that succeeded
+            unsigned long long every_S = 1ull; // bits 0, S, 2S, ...
+            for (uint32_t w = S; w < 64u; w <<= 1) every_S |= every_S << w;
+            const unsigned long long mine = mine_waits ? ((ok >> rank) & every_S) : 0ull;
+            const uint32_t helper = rank + (uint32_t)__builtin_ctzll(mine | (1ull << 63));
+            const uint32_t addr = (helper & 63u) << 2;
+            const V3 got = v3(lane_fetch(cand.x, addr), lane_fetch(cand.y, addr), lane_fetch(cand.z, addr));
+            if (mine != 0ull) p = got;
+            waiting &= ~__builtin_amdgcn_ballot_w64(mine != 0ull);
+            base += 64u >> shift;
         }
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     }
     return p;
 }
@@ -733,11 +782,23 @@ __device__ __forceinline__ double reflectance(double cosine, double refraction_i
     return r0 + (1.0 - r0) * (m * m4);
 }
 
-// Material::scatter for the hit (point p, unit-or-not normal n already flipped to oppose the ray), drawing from stream
-// (pixel, sample, stream) of the key (k0, k1).  Returns false when the path ends (no scatter).  attenuation is
-// evaluated by the caller via texture_value.  Lambertian and Metal share one instance of the unit-sphere sampler.
-__device__ __forceinline__ bool scatter(uint32_t mat_type, double mat_param, V3 ray_d, V3 n, bool front_face, uint32_t pixel,
-                                        uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1, V3& out_d, bool& textured) {
+// Material::scatter (material.rs), split where the unit-sphere sample is needed so that the sampler can be run by the
+// whole wave (random_in_unitsphere_wave):  scatter_begin decides per lane what happens -- Dielectric scatters at once
+// (one draw of its own), DiffuseLight and an absorbed Metal reflection end the path, Lambertian and a surviving Metal
+// reflection ask for a point (`need`) and leave the vector it will be added to in `base` -- and scatter_finish turns
+// the point into the scattered direction.  n is the hit normal already flipped to oppose the ray; the random draws come
+// from stream (pixel, sample, stream) of the key (k0, k1).
+enum { PT_SCATTER_NONE = 0, PT_SCATTER_DONE = 1, PT_SCATTER_NEED_POINT = 2 };
+__device__ __forceinline__ int scatter_begin(uint32_t mat_type, double mat_param, V3 ray_d, V3 n, bool front_face, uint32_t pixel,
+                                             uint32_t sample, uint32_t stream, uint32_t k0, uint32_t k1, V3& out_d, V3& base) {
+    if (mat_type == PT_MAT_LAMBERTIAN) { // material.rs:41-55
+        base = n;
+        return PT_SCATTER_NEED_POINT;
+    }
+    if (mat_type == PT_MAT_METAL) { // material.rs:77-93
+        base = reflect(unit_vector(ray_d), n);
+        return dot(base, n) > 0.0 ? PT_SCATTER_NEED_POINT : PT_SCATTER_NONE;
+    }
     if (mat_type == PT_MAT_DIELECTRIC) { // material.rs:117-143
         double refraction_ratio = front_face ? 1.0 / mat_param : mat_param;
         V3 unit_direction = unit_vector(ray_d);
@@ -751,26 +812,15 @@ __device__ __forceinline__ bool scatter(uint32_t mat_type, double mat_param, V3 
             reflects = reflectance(cos_theta, refraction_ratio) > (double)(bits >> 11) * (1.0 / 9007199254740992.0);
         }
         out_d = reflects ? reflect(unit_direction, n) : refract(unit_direction, n, refraction_ratio);
-        textured = false; // attenuation (1,1,1)
-        return true;
+        return PT_SCATTER_DONE;
     }
-    if (mat_type != PT_MAT_LAMBERTIAN && mat_type != PT_MAT_METAL) return false; // DiffuseLight never scatters (material.rs:16-18)
-    const bool metal = mat_type == PT_MAT_METAL;
-    V3 reflected = v3(0.0, 0.0, 0.0);
-    if (metal) { // material.rs:77-93
-        reflected = reflect(unit_vector(ray_d), n);
-        if (!(dot(reflected, n) > 0.0)) return false;
-    }
-    const V3 s = random_in_unitsphere_stream(pixel, sample, stream, k0, k1);
-    if (metal) {
-        out_d = reflected + mat_param * s;
-    } else { // material.rs:41-55
-        V3 dir = n + unit_vector(s);
-        if (near_zero(dir)) dir = n;
-        out_d = dir;
-    }
-    textured = true;
-    return true;
+    return PT_SCATTER_NONE; // DiffuseLight never scatters (material.rs:16-18)
+}
+__device__ __forceinline__ V3 scatter_finish(uint32_t mat_type, double mat_param, V3 base, V3 point) {
+    if (mat_type == PT_MAT_METAL) return base + mat_param * point; // material.rs:84: reflected + fuzz * random_in_unit_sphere
+    V3 dir = base + unit_vector(point);                              // material.rs:47: normal + random_unit_vector
+    if (near_zero(dir)) dir = base;
+    return dir;
 }
 
 // ------------------------------------------------------------------ stream layouts

@@ -53,12 +53,18 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
     const bool last_bounce = (a.bounce + 1u >= a.max_bounces);
     const bool has_bg = (a.bg[0] != 0.f) || (a.bg[1] != 0.f) || (a.bg[2] != 0.f);
     uint32_t out_n = 0; // survivors this wave has written so far (wave-uniform)
+    __shared__ uint2 s_exchange[PT_BLOCK]; // 64 slots per wave for the cooperative sampler
+    uint2* exchange = s_exchange + (threadIdx.x & ~63u);
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32), stream = a.bounce + 1u;
     for (uint32_t first = 0; first < n; first += 64u) {
         const uint32_t k = first + lane;
         const size_t i = region_base + k;
-        bool alive = false;
-        V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0);
+        bool alive = false, need_point = false;
+        V3 next_o = v3(0, 0, 0), next_d = v3(0, 0, 0), base = v3(0, 0, 0);
         uint4 st = make_uint4(0, 0, 0, 0);
+        uint32_t pixel = 0, sample = 0, mat_type = PT_MAT_DIFFUSE_LIGHT;
+        double mat_param = 0.0;
+        // ---- per lane: the hit record, emission, and what the material does next
         if (k < n) {
             // all six stream loads are issued together: one memory latency, not a chain of them
             st = a.state_in[i];
@@ -76,18 +82,23 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
                 if (sp.prim_type == PT_PRIM_SPHERE) n_out = (p - n_out) / sp.g[3]; // geometry.rs:151
                 bool front = dot(d, n_out) < 0.0;                        // geometry.rs:29
                 V3 nn = front ? n_out : neg(n_out);                      // geometry.rs:33-37
-                // ONE texture lookup per hit: the light's emission (material.rs:158-166) or the scatterer's albedo
-                bool emits = false, textured = false;
+                bool emits = false;
                 if (sp.mat_type == PT_MAT_DIFFUSE_LIGHT) {
                     emits = front;
                 } else if (!last_bounce) {
                     uint32_t slot = st.x / a.npix;
-                    uint32_t pixel = st.x - slot * a.npix;
-                    alive = scatter(sp.mat_type, sp.param, d, nn, front, pixel, a.sample_base + slot, a.bounce + 1u, (uint32_t)a.seed,
-                                    (uint32_t)(a.seed >> 32), next_d, textured);
+                    pixel = st.x - slot * a.npix;
+                    sample = a.sample_base + slot;
+                    mat_type = sp.mat_type;
+                    mat_param = sp.param;
+                    const int what = scatter_begin(mat_type, mat_param, d, nn, front, pixel, sample, stream, k0, k1, next_d, base);
+                    alive = what != PT_SCATTER_NONE;
+                    need_point = what == PT_SCATTER_NEED_POINT;
                     next_o = p;
                 }
-                if (emits || (alive && textured)) {
+                // ONE texture lookup per hit: the light's emission (material.rs:158-166) or the scatterer's albedo
+                // (Lambertian / Metal attenuation, material.rs:48-53,86-91; a Dielectric's is (1,1,1))
+                if (emits || need_point) {
                     float cr = sp.color[0], cg = sp.color[1], cb = sp.color[2];
                     if (PROCEDURAL && !sp.tex_solid) {
                         V3 c = texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, sp.texture, p);
@@ -104,6 +115,17 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
             }
         }
         if (last_bounce) continue; // nothing survives the last bounce
+        // ---- the wave: unit-sphere points for the lanes that asked (vec3.rs:41-49), then their scattered directions
+        if (wave_any(need_point)) {
+#ifdef PT_ABLATE_NO_SAMPLER
+            const V3 point = v3(0.3 + 1e-9 * pixel, 0.4, 0.5 - 1e-9 * sample);
+#elif defined(PT_ABLATE_ONE_ROUND)
+            V3 point; bool acc_; unitsphere_pair(pixel, sample, stream, 0u, k0, k1, point, acc_);
+#else
+            const V3 point = random_in_unitsphere_wave(need_point, pixel, sample, stream, k0, k1, exchange);
+#endif
+            if (need_point) next_d = scatter_finish(mat_type, mat_param, base, point);
+        }
         // ---- stream compaction inside the wave's own region: rank by ballot + mbcnt, append at the running offset
         const unsigned long long mask = __ballot(alive);
         const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
