@@ -188,6 +188,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    # one more, untimed, frame on a single stream: the same kernels without the overlap between lanes, for an
+    # isolated per-kernel roofline next to the co-run one of the timed region
+    iso = None
+    if world == 1 and not args.lanes:
+        ctx.set_option("lanes", 1)
+        iso, _ = step()
+        ctx.set_option("lanes", 2)
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,13 +215,30 @@ def main():
         else:
             kname, kms, kbytes, klaunches = "shade_kernel", ms_shade, shade_in * BYTES_SHADE_IN + shade_out * BYTES_SHADE_OUT, n_shade
         achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # HBM bytes from the PMC counters (profiles/pmc_summary.json, collected by profiles/collect_pmc.sh on this
+        # scene at 16 spp and corrected as MI355X_MICROARCH.md prescribes): stored per ray, scaled to this launch size
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.scene == "CornellBox":
             try:
-                traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+                per_ray = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_ray")
+                if per_ray is not None:
+                    traffic = int(per_ray * rays / max(1, klaunches))
             except Exception:
                 traffic = None
+        isolated = None
+        if iso is not None:
+            if kname == "trace_kernel":
+                ims, ibytes, il = iso.ms_trace, iso.rays * BYTES_TRACE, iso.launches_trace
+            else:
+                ims = iso.ms_shade
+                ibytes = iso.rays * BYTES_SHADE_IN + (iso.rays - list(iso.rays_per_bounce)[0]) * BYTES_SHADE_OUT
+                il = iso.launches_shade
+            ia = ibytes / (ims * 1e-3) / 1e9 if ims > 0 else 0.0
+            isolated = {"achieved": round(ia, 2), "frac": round(ia / HBM_PEAK_GBS, 5), "avg_launch_ms": round(ims / max(1, il), 5),
+                        "kernel_ms_per_step": {"raygen": round(iso.ms_raygen, 3), "trace": round(iso.ms_trace, 3),
+                                               "shade": round(iso.ms_shade, 3), "fold": round(iso.ms_fold, 3)},
+                        "note": "one untimed frame with lanes=1 (no overlap between sub-passes)"}
         out = {
             "metric": "Mrays/s (ray segments = hit queries per second), CornellBox 1080p 256spp; ms_per_step = s/frame*1e3",
             "value": round(mrays, 2),
@@ -241,6 +266,7 @@ def main():
                 "avg_launch_ms": round(kms / max(1, klaunches), 5),
                 "bytes_per_launch": int(kbytes / max(1, klaunches)),
                 "pipeline_frac": round(mrays * 1e6 * BYTES_SEGMENT / world / (HBM_PEAK_GBS * 1e9), 5),
+                "isolated": isolated,
             },
             "kernel_ms_per_step": {"raygen": round(ms_raygen / args.steps, 3), "trace": round(ms_trace / args.steps, 3),
                                    "shade": round(ms_shade / args.steps, 3), "fold": round(ms_fold / args.steps, 3),
