@@ -153,6 +153,9 @@ const char* pt_last_error(const PtContext* ctx);
  * "lanes" (1..4: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
  *   trace overlaps another's shade; default 2), "lane_sync" (1 = lanes advance in lock step through events; default 0
  *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid; default 1),
+ * "trace_mode" (which kernel answers the hit queries, applied at the next pt_scene_upload: -1 = by scene size, 0 = wave-uniform
+ *   lockstep walk, 1 = per-lane walk with an LDS stack, 2 = per-lane stackless walk of the record stream; all three give
+ *   identical results),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 

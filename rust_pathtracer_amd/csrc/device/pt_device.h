@@ -229,6 +229,7 @@ enum { PT_WK_NODE = 0, PT_WK_RECT_XY = 1, PT_WK_RECT_XZ = 2, PT_WK_RECT_YZ = 3, 
 #define PT_WK_TRIANGLE_BYTES 80u
 #define PT_WALK_MAX_ITEMS 192 /* nodes + primitives: the stream stays within the scalar cache */
 #define PT_WALK_PLANES_IN_RANGE 1u /* walk_flags: see walk_division_is_proven */
+enum { PT_TRACE_LOCKSTEP = 0, PT_TRACE_STACK = 1, PT_TRACE_STREAM = 2 };
 // Everything shade needs about the primitive it hit, in ONE 80-byte record (one dependent fetch instead of the
 // chain primitive -> material -> texture): the geometry the normal comes from, the material, and the colour
 // when the material's texture is a solid one.
@@ -258,8 +259,9 @@ struct DevScene {
     uint32_t lds_nodes; // nodes [0, lds_nodes) are staged in LDS by the trace kernel
     uint32_t lds_prims; // primitives [0, lds_prims) likewise (all of them for small scenes)
     uint32_t stack_depth;
-    const unsigned char* walk; // non-null when the scene is small enough for the wave-uniform walk
+    const unsigned char* walk; // the record stream (PT_WK_*), padded by 64 bytes
     uint32_t walk_bytes;
+    uint32_t trace_mode; // PT_TRACE_*: which kernel walks it
     uint32_t walk_flags; // PT_WALK_*
     uint32_t has_procedural; // any checker / marble texture
     const ShadePrim* shade_prims;
@@ -664,6 +666,106 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
         }
     }
 }
+
+// ------------------------------------------------------------------ the same record stream, one lane per ray
+// Larger scenes: every lane walks the pre-order stream on its own.  A node whose box the ray misses is left through its
+// skip offset, anything else by stepping to the next record -- the depth-first, left-before-right order of
+// bvh.rs:107-121 without a stack: no per-lane stack in LDS, no child references, one 56-byte fetch per step (header +
+// 48 bytes of payload, issued together; only a triangle needs a second one).  The walk is a small state machine
+// (StreamWalk) so that the render kernel can hand a lane its next ray the moment it finishes one.
+struct StreamWalk {
+    V3 o, d, inv;
+    double t_min, best_t;
+    int32_t best_prim;
+    uint32_t off;      // byte offset of the current record
+    uint32_t kind, aux; // its header
+    double g[6];       // and the first 48 bytes of its payload
+#ifdef PT_DEBUG_STEPS
+    uint32_t steps_nodes, steps_leaves;
+#endif
+    __device__ __forceinline__ void fetch(const unsigned char* __restrict__ stream) {
+        const uint2 hdr = *reinterpret_cast<const uint2*>(stream + off);
+        const double2* q = reinterpret_cast<const double2*>(stream + off + 8u);
+        const double2 a = q[0], b = q[1], c = q[2]; // within the stream's padding for the last record (and past the end: zeros)
+        kind = hdr.x; aux = hdr.y;
+        g[0] = a.x; g[1] = a.y; g[2] = b.x; g[3] = b.y; g[4] = c.x; g[5] = c.y;
+    }
+    __device__ __forceinline__ void begin(const unsigned char* __restrict__ stream, V3 o_, V3 d_, double t_min_, double t_max_) {
+        o = o_; d = d_;
+        inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        t_min = t_min_; best_t = t_max_;
+        best_prim = -1;
+        off = 0;
+#ifdef PT_DEBUG_STEPS
+        steps_nodes = steps_leaves = 0;
+#endif
+        fetch(stream);
+    }
+    __device__ __forceinline__ bool at_node() const { return kind == PT_WK_NODE; }
+    __device__ __forceinline__ void accept(bool hit, double t, uint32_t prim) {
+        if (hit) { best_t = t; best_prim = (int32_t)prim; }
+    }
+    // the current record is a node: bvh.rs:108-110 (straight-line box test: no divergent early returns)
+    __device__ __forceinline__ void step_node(const unsigned char* __restrict__ stream) {
+#ifdef PT_DEBUG_STEPS
+        steps_nodes += 1;
+#endif
+        double lo = t_min, hi = best_t;
+        double t0 = (g[0] - o.x) * inv.x, t1 = (g[3] - o.x) * inv.x;
+        lo = fmax((inv.x < 0.0) ? t1 : t0, lo); hi = fmin((inv.x < 0.0) ? t0 : t1, hi);
+        bool miss = hi <= lo;
+        t0 = (g[1] - o.y) * inv.y; t1 = (g[4] - o.y) * inv.y;
+        lo = fmax((inv.y < 0.0) ? t1 : t0, lo); hi = fmin((inv.y < 0.0) ? t0 : t1, hi);
+        miss |= hi <= lo;
+        t0 = (g[2] - o.z) * inv.z; t1 = (g[5] - o.z) * inv.z;
+        lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
+        miss |= hi <= lo;
+        off = miss ? aux : off + PT_WK_NODE_BYTES;
+        fetch(stream);
+    }
+    // the current record is a primitive (or the six sides of a box)
+    __device__ __forceinline__ void step_leaf(const unsigned char* __restrict__ stream) {
+#ifdef PT_DEBUG_STEPS
+        steps_leaves += 1;
+#endif
+        double t;
+        if (kind == PT_WK_SPHERE) {
+            accept(hit_sphere(g, o, d, t_min, best_t, t), t, aux);
+            off += PT_WK_SPHERE_BYTES;
+        } else if (kind == PT_WK_TRIANGLE) {
+            const double* rest = reinterpret_cast<const double*>(stream + off + 56u);
+            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], rest[0], rest[1], rest[2]};
+            accept(hit_triangle(tri, o, d, t_min, best_t, t), t, aux);
+            off += PT_WK_TRIANGLE_BYTES;
+        } else if (kind == PT_WK_BOX6) { // geometry.rs:70-83 over the six sides, in list order
+            const double r0[5] = {g[2], g[0], g[3], g[1], g[4]}, r1[5] = {g[5], g[0], g[3], g[1], g[4]};
+            const double r2[5] = {g[1], g[0], g[3], g[2], g[5]}, r3[5] = {g[4], g[0], g[3], g[2], g[5]};
+            const double r4[5] = {g[0], g[1], g[4], g[2], g[5]}, r5[5] = {g[3], g[1], g[4], g[2], g[5]};
+            accept(hit_rect(r0, o.z, d.z, o.x, d.x, o.y, d.y, t_min, best_t, t), t, aux);
+            accept(hit_rect(r1, o.z, d.z, o.x, d.x, o.y, d.y, t_min, best_t, t), t, aux + 1u);
+            accept(hit_rect(r2, o.y, d.y, o.x, d.x, o.z, d.z, t_min, best_t, t), t, aux + 2u);
+            accept(hit_rect(r3, o.y, d.y, o.x, d.x, o.z, d.z, t_min, best_t, t), t, aux + 3u);
+            accept(hit_rect(r4, o.x, d.x, o.y, d.y, o.z, d.z, t_min, best_t, t), t, aux + 4u);
+            accept(hit_rect(r5, o.x, d.x, o.y, d.y, o.z, d.z, t_min, best_t, t), t, aux + 5u);
+            off += PT_WK_BOX6_BYTES;
+        } else {
+            bool h;
+            if (kind == PT_WK_RECT_XY) h = hit_rect(g, o.z, d.z, o.x, d.x, o.y, d.y, t_min, best_t, t);
+            else if (kind == PT_WK_RECT_XZ) h = hit_rect(g, o.y, d.y, o.x, d.x, o.z, d.z, t_min, best_t, t);
+            else h = hit_rect(g, o.x, d.x, o.y, d.y, o.z, d.z, t_min, best_t, t);
+            accept(h, t, aux);
+            off += PT_WK_RECT_BYTES;
+        }
+        fetch(stream);
+    }
+    __device__ __forceinline__ double result_t() const {
+#ifdef PT_DEBUG_STEPS
+        return (double)steps_nodes + 1e-4 * (double)steps_leaves; // debugging aid: step counts instead of t
+#else
+        return best_t;
+#endif
+    }
+};
 
 __device__ __forceinline__ void traverse_walk(const unsigned char* __restrict__ walk, uint32_t walk_bytes, uint32_t walk_flags,
                                               bool lane_live, V3 o, V3 d, double t_min, double t_max, double& best_t,

@@ -56,6 +56,7 @@ struct PtContext {
     int64_t paths_per_pass = (int64_t)1 << 27;
     int profile = 1;
     int blocks_per_cu_override = 0;
+    int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
     int repack_every = 0, repack_first = 8;  // measured on Cornell 1080p: the copy costs more than the fuller waves save
     std::vector<hipEvent_t> events;
 
@@ -320,6 +321,9 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
     } else if (k == "repack_first") {  // first bounce before which a repack runs
         if (value < 1 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "repack_first out of range");
         ctx->repack_first = (int)value;
+    } else if (k == "trace_mode") {  // -1 automatic, 0 lockstep walk, 1 per-lane stack (LDS), 2 per-lane record stream; next upload
+        if (value < -1 || value > 2) return ctx->fail(PT_ERR_BAD_ARG, "trace_mode out of range [-1, 2]");
+        ctx->trace_mode_override = (int)value;
     } else if (k == "blocks_per_cu") {  // tuning knob: persistent-grid blocks (of 4 waves) per CU; takes effect at the next upload
         if (value < 0 || value > 16) return ctx->fail(PT_ERR_BAD_ARG, "blocks_per_cu out of range [0, 16]");
         ctx->blocks_per_cu_override = (int)value;
@@ -469,7 +473,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     // small scenes: the pre-order record stream of the wave-uniform walk (pt_device.h traverse_walk)
     std::vector<uint64_t> walk; // 8-byte words; a record = {kind | aux << 32} + payload doubles
     uint32_t walk_flags = PT_WALK_PLANES_IN_RANGE;
-    if ((uint64_t)s->n_nodes + s->n_prims <= PT_WALK_MAX_ITEMS) {
+    {
         auto put_header = [&](uint32_t kind, uint32_t aux_word) { walk.push_back((uint64_t)kind | ((uint64_t)aux_word << 32)); };
         auto put = [&](double v) {
             uint64_t bits;
@@ -550,7 +554,10 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     ctx->has_scene = false;
     PT_HIP(ctx, ensure_buf(ctx->d_shade, shade_prims.size() * sizeof(ShadePrim)));
     PT_HIP(ctx, hipMemcpy(ctx->d_shade.p, shade_prims.data(), shade_prims.size() * sizeof(ShadePrim), hipMemcpyHostToDevice));
-    if (!walk.empty()) {
+    if (walk.size() * sizeof(uint64_t) >= 0xFFFFFF00ull) return ctx->fail(PT_ERR_BAD_ARG, "pt_scene_upload: scene too large (record stream over 4 GiB)");
+    const size_t walk_words = walk.size();
+    for (int k = 0; k < 8; ++k) walk.push_back(0); // the per-lane walk fetches 56 bytes per record whatever its kind
+    {
         PT_HIP(ctx, ensure_buf(ctx->d_walk, walk.size() * sizeof(uint64_t)));
         PT_HIP(ctx, hipMemcpy(ctx->d_walk.p, walk.data(), walk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     }
@@ -582,8 +589,12 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.n_textures = s->n_textures;
     sc.root = 0;  // the root is first in breadth-first order
     sc.stack_depth = tc.max_depth;
-    sc.walk = walk.empty() ? nullptr : (const unsigned char*)ctx->d_walk.p;
-    sc.walk_bytes = (uint32_t)(walk.size() * sizeof(uint64_t));
+    sc.walk = (const unsigned char*)ctx->d_walk.p;
+    sc.walk_bytes = (uint32_t)(walk_words * sizeof(uint64_t));
+    // which kernel walks it: the wave-uniform walk while the stream fits the scalar cache, one lane per ray beyond
+    const bool small = (uint64_t)s->n_nodes + s->n_prims <= PT_WALK_MAX_ITEMS;
+    sc.trace_mode = small ? PT_TRACE_LOCKSTEP : PT_TRACE_STREAM;
+    if (ctx->trace_mode_override >= 0) sc.trace_mode = (uint32_t)ctx->trace_mode_override;
     sc.walk_flags = walk_flags;
     sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
     sc.has_procedural = 0;
@@ -608,7 +619,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     g.trace_lds_bytes = (size_t)sc.lds_nodes * sizeof(DevNode) + (size_t)sc.lds_prims * sizeof(DevPrim) + stack_bytes;
     // Waves per CU of the persistent grid: 32 (8 per SIMD) when every kernel of the pass fits 8 waves per SIMD (small
     // scene, solid textures); otherwise 24, a whole number of rounds for kernels that fit 6, 3 or 2 (no ragged last round).
-    uint32_t blocks_per_cu = (sc.walk && !sc.has_procedural) ? 8u : 6u;
+    uint32_t blocks_per_cu = (sc.trace_mode != PT_TRACE_STACK && !sc.has_procedural) ? 8u : 6u;
     if (ctx->blocks_per_cu_override > 0) blocks_per_cu = (uint32_t)ctx->blocks_per_cu_override;
     g.grid = (uint32_t)ctx->cu_count * blocks_per_cu;
     ctx->has_scene = true;

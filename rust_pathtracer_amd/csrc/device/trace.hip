@@ -73,9 +73,68 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const unsigned cha
     }
 }
 
+// Larger scenes: one lane per ray over the same record stream (pt_device.h StreamWalk).  No LDS.
+// Rays differ widely in the number of records they visit (SphereField: 40 on average, 120 for the slowest of 64), so a
+// lane does not wait for its wave: whenever PT_REFILL_LANES lanes are out of work, each takes the next unassigned ray of the
+// wave's region (rank among the idle lanes by ballot + mbcnt; the region is private to the wave, so no atomics).
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 16
+#endif
+#ifndef PT_LEAF_LANES
+#define PT_LEAF_LANES 24
+#endif
+__global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned char* __restrict__ stream, uint32_t stream_bytes, RayStream rays,
+                                                                const uint32_t* __restrict__ counts, uint32_t n_waves,
+                                                                double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
+    const uint32_t wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(counts[wave]);
+    const size_t base = (size_t)wave * counts[n_waves];
+    uint32_t next = 0; // first ray of the region not yet handed to a lane (wave-uniform)
+    bool busy = false;
+    size_t mine = 0;
+    StreamWalk w;
+    w.begin(stream, v3(0, 0, 0), v3(1, 1, 1), 0.0, 0.0);
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!busy);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (next < n && n_idle >= PT_REFILL_LANES) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t k = next + rank;
+            if (!busy && k < n) {
+                mine = base + k;
+                const double2 a = rays.a[mine], b = rays.b[mine], c = rays.c[mine];
+                w.begin(stream, v3(a.x, a.y, b.x), v3(b.y, c.x, c.y), 0.001, __builtin_huge_val()); // ray.rs:25
+                busy = true;
+            }
+            next = min(n, next + n_idle);
+        } else if (n_idle == 64u) {
+            break; // nothing in flight, nothing left to hand out
+        }
+        // The wave runs box tests and primitive tests as separate phases: lanes that have reached a primitive wait (a
+        // ray meets ~5 nodes per primitive) until PT_LEAF_LANES of them have gathered or nobody is at a node any more.
+        const unsigned long long at_node = __builtin_amdgcn_ballot_w64(busy && w.at_node());
+        const unsigned long long at_leaf = __builtin_amdgcn_ballot_w64(busy && !w.at_node());
+        if (at_node != 0ull && (uint32_t)__builtin_popcountll(at_leaf) < PT_LEAF_LANES) {
+            if (busy && w.at_node()) w.step_node(stream);
+        } else {
+            if (busy && !w.at_node()) w.step_leaf(stream);
+        }
+        if (busy && w.off >= stream_bytes) {
+            hit_t[mine] = w.result_t();
+            hit_prim[mine] = w.best_prim;
+            busy = false;
+        }
+    }
+}
+
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io) {
     const RayStream& in = wf.rays[io.in];
-    if (sc.walk) {
+    if (sc.trace_mode == PT_TRACE_STREAM) {
+        hipLaunchKernelGGL(trace_stream_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.walk_bytes, in, io.counts_in, wf.n_waves,
+                           wf.hit_t, wf.hit_prim);
+        return;
+    }
+    if (sc.trace_mode == PT_TRACE_LOCKSTEP) {
         hipLaunchKernelGGL(trace_walk_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.walk_bytes, sc.walk_flags, in, io.counts_in, wf.n_waves,
                            wf.hit_t, wf.hit_prim);
         return;
@@ -164,12 +223,33 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_walk_kernel(DevScene sc,
     }
 }
 
+__global__ __launch_bounds__(PT_BLOCK) void trace_batch_stream_kernel(DevScene sc, const double* __restrict__ origins,
+                                                                      const double* __restrict__ dirs, uint32_t n, double t_min,
+                                                                      double t_max, PtHitOut* __restrict__ out) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        V3 o = v3(origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]);
+        V3 d = v3(dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]);
+        StreamWalk w;
+        w.begin(sc.walk, o, d, t_min, t_max);
+        while (w.off < sc.walk_bytes) {
+            if (w.at_node()) w.step_node(sc.walk);
+            else w.step_leaf(sc.walk);
+        }
+        write_hit_record(sc, o, d, w.result_t(), w.best_prim, out + i);
+    }
+}
+
 void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const double* origins, const double* dirs,
                         uint32_t n, double t_min, double t_max, PtHitOut* out) {
     uint32_t blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) blocks = 1;
-    if (sc.walk) {
+    if (sc.trace_mode == PT_TRACE_STREAM) {
+        hipLaunchKernelGGL(trace_batch_stream_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, sc, origins, dirs, n, t_min, t_max, out);
+        return;
+    }
+    if (sc.trace_mode == PT_TRACE_LOCKSTEP) {
         hipLaunchKernelGGL(trace_batch_walk_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, sc, origins, dirs, n, t_min, t_max, out);
         return;
     }

@@ -134,6 +134,30 @@ def test_trace_edge_cases(gpu_ctx, oracle):
         assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_every_trace_kernel_gives_the_same_hits(gpu_ctx, oracle, mode):
+    """The three walkers of the record stream / node table -- wave-uniform lockstep (0), per-lane with an LDS stack (1),
+    per-lane stackless over the stream (2) -- forced in turn on a world that would normally take the per-lane stream
+    walk and on one that would take the lockstep walk."""
+    try:
+        gpu_ctx.set_option("trace_mode", mode)
+        for seed, n_objects, mesh in [(21, 60, True), (22, 12, False)]:
+            s, o = su.random_world(seed, n_objects=n_objects, with_mesh=mesh)
+            gpu_ctx.upload(s)
+            ro, rd = su.random_rays(seed + 1, 40000)
+            p2, d2 = su.bounce_rays(o, ro, rd, seed + 2)
+            ro, rd = np.concatenate([ro, p2]), np.concatenate([rd, d2])
+            prim, t, normal, front = o.trace(ro, rd)
+            assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
+            w, h, bg = 48, 32, (0.6, 0.7, 0.9)
+            cam = api.camera_new((13.0, 6.0, 9.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, w / h, 0.0, 10.0)
+            stats, got, want, rays = render_pair(gpu_ctx, o, cam, w, h, bg, 0, 3, 12, 5)
+            assert stats.rays == rays
+            assert_images_close(got, want, 3)
+    finally:
+        gpu_ctx.set_option("trace_mode", -1)
+
+
 def _box_world(tiny_plane):
     """Rectangles and boxes only (the lockstep walk's fast paths), optionally with plane coordinates far outside the
     range in which the walk forms quotients from reciprocals (pt_device.h walk_division_is_proven)."""
