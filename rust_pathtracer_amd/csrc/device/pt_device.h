@@ -254,6 +254,7 @@ struct DevScene {
     const PtMaterial* materials;
     const PtTexture* textures;
     const uint8_t* perlin;
+    uint32_t n_perlin; // 256-byte permutation tables
     uint32_t n_nodes, n_prims, n_materials, n_textures;
     uint32_t root;
     uint32_t lds_nodes; // nodes [0, lds_nodes) are staged in LDS by the trace kernel
@@ -809,7 +810,7 @@ __device__ __forceinline__ int perlin_hash(const uint8_t* perm, long x, long y, 
     return perm[b ^ (int)(z & 0xff)];
 }
 __device__ __forceinline__ double perlin_quintic(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
-__device__ inline double perlin_get(const uint8_t* perm, double px, double py, double pz) {
+__device__ __forceinline__ double perlin_get(const uint8_t* perm, double px, double py, double pz) {
     double fx = floor(px), fy = floor(py), fz = floor(pz);
     long cx = (long)fx, cy = (long)fy, cz = (long)fz;
     double dx = px - fx, dy = py - fy, dz = pz - fz;
@@ -837,7 +838,10 @@ __device__ inline double perlin_get(const uint8_t* perm, double px, double py, d
     return r;
 }
 // Texture::value (texture.rs:19-23, :36-45, :75-80); u,v are unused by every texture the reference ships.
-__device__ __noinline__ V3 texture_value_procedural(const PtTexture* textures, uint32_t n_textures, const uint8_t* perlin,
+#ifndef PT_TEXTURE_CALL
+#define PT_TEXTURE_CALL __forceinline__
+#endif
+__device__ PT_TEXTURE_CALL V3 texture_value_procedural(const PtTexture* textures, uint32_t n_textures, const uint8_t* perlin,
                                                     uint32_t tex, V3 p) {
     for (uint32_t guard = 0; guard <= n_textures; ++guard) {
         const PtTexture* t = textures + tex;
@@ -862,8 +866,8 @@ __device__ __noinline__ V3 texture_value_procedural(const PtTexture* textures, u
     }
     return v3(0.0, 0.0, 0.0);
 }
-// Solid colours (every material of the Cornell box) are answered inline; checker and marble go through ONE
-// out-of-line body so their sin() and noise code is not replicated at every call site.
+// Solid colours (every material of the Cornell box) are answered inline; checker and marble have ONE call site per kernel
+// (shade looks a texture up once per hit), inlined so that the permutation tables can be read from LDS.
 // PROCEDURAL = false is for scenes whose textures are all solid: the kernel then carries neither the call nor the
 // callee's register budget.
 template <bool PROCEDURAL>

@@ -583,6 +583,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.materials = (const PtMaterial*)ctx->d_mats.p;
     sc.textures = (const PtTexture*)ctx->d_texs.p;
     sc.perlin = (const uint8_t*)ctx->d_perlin.p;
+    sc.n_perlin = s->n_perlin_tables;
     sc.n_nodes = s->n_nodes;
     sc.n_prims = s->n_prims;
     sc.n_materials = s->n_materials;

@@ -10,6 +10,8 @@
 // Reads 76 B/ray (ray 48, hit 12, state 16), writes 64 B per surviving ray (ray 48, state 16).
 #include "pt_launch.h"
 
+#define PT_PERLIN_LDS_TABLES 16
+
 struct ShadeArgs {
     RayStream in, out;
     const uint4* state_in;
@@ -39,12 +41,20 @@ __device__ __forceinline__ void add_radiance(float4* plane, uint32_t path, float
 template <bool PROCEDURAL, bool TABLE_LDS>
 __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
+    // marble's seven octaves make 168 dependent byte look-ups in a 256-byte permutation table: from LDS, not from L2
+    __shared__ __align__(16) uint8_t s_perlin[PROCEDURAL ? PT_PERLIN_LDS_TABLES * 256 : 16];
+    const bool perlin_in_lds = PROCEDURAL && sc.n_perlin <= PT_PERLIN_LDS_TABLES;
     if (TABLE_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.shade_prims);
         uint4* dst = reinterpret_cast<uint4*>(s_table);
         for (uint32_t k = threadIdx.x; k < sc.n_prims * 5u; k += PT_BLOCK) dst[k] = src[k];
-        __syncthreads();
     }
+    if (perlin_in_lds) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.perlin);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_perlin);
+        for (uint32_t k = threadIdx.x; k < sc.n_perlin * 64u; k += PT_BLOCK) dst[k] = src[k];
+    }
+    if (TABLE_LDS || perlin_in_lds) __syncthreads();
     const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = __builtin_amdgcn_readfirstlane(a.counts_in[wave]);
@@ -101,7 +111,8 @@ __global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs 
                 if (emits || need_point) {
                     float cr = sp.color[0], cg = sp.color[1], cb = sp.color[2];
                     if (PROCEDURAL && !sp.tex_solid) {
-                        V3 c = texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, sp.texture, p);
+                        V3 c = perlin_in_lds ? texture_value_procedural(sc.textures, sc.n_textures, s_perlin, sp.texture, p)
+                                             : texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, sp.texture, p);
                         cr = (float)c.x; cg = (float)c.y; cb = (float)c.z;
                     }
                     if (emits) {
