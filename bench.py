@@ -29,7 +29,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_TRACE = 60       # per ray: read o,d 48 B + write t,prim 12 B              
 BYTES_SHADE_IN = 76    # per ray: ray 48 + hit 12 + state 16
 BYTES_SHADE_OUT = 64   # per surviving ray: next ray 48 + state 16
-BYTES_SEGMENT = 200    # whole pipeline per ray segment
+BYTES_SEGMENT = 200    # whole pipeline per ray segment with separate trace and shade kernels
+BYTES_PATH_IN = 64     # fused path kernel, per ray: ray 48 + state 16 (the hit record stays in registers)
 
 
 def parse_args():
@@ -168,8 +169,8 @@ def main():
     fence()
     t0 = time.perf_counter()
     rays = 0
-    ms_trace = ms_shade = ms_raygen = ms_fold = ms_repack = 0.0
-    n_trace = n_shade = 0
+    ms_trace = ms_shade = ms_raygen = ms_fold = ms_repack = ms_path = 0.0
+    n_trace = n_shade = n_path = 0
     shade_in = shade_out = 0
     img = None
     for _ in range(args.steps):
@@ -180,6 +181,8 @@ def main():
         ms_raygen += st.ms_raygen
         ms_fold += st.ms_fold
         ms_repack += st.ms_repack
+        ms_path += st.ms_path
+        n_path += st.launches_path
         n_trace += st.launches_trace
         n_shade += st.launches_shade
         rpb = list(st.rays_per_bounce)
@@ -210,7 +213,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_total / elapsed / 1e6
         # roofline of the dominant kernel on rank 0, from HIP-event times on the library's stream
-        if ms_trace >= ms_shade:
+        if ms_path > 0:
+            # the fused kernel keeps the hit record in registers: it has to move 64 B per ray in and 64 B per survivor out
+            kname, kms, kbytes, klaunches = "path_kernel", ms_path, shade_in * BYTES_PATH_IN + shade_out * BYTES_SHADE_OUT, n_path
+        elif ms_trace >= ms_shade:
             kname, kms, kbytes, klaunches = "trace_kernel", ms_trace, rays * BYTES_TRACE, n_trace
         else:
             kname, kms, kbytes, klaunches = "shade_kernel", ms_shade, shade_in * BYTES_SHADE_IN + shade_out * BYTES_SHADE_OUT, n_shade
@@ -228,7 +234,10 @@ def main():
                 traffic = None
         isolated = None
         if iso is not None:
-            if kname == "trace_kernel":
+            if kname == "path_kernel":
+                ims, il = iso.ms_path, iso.launches_path
+                ibytes = iso.rays * BYTES_PATH_IN + (iso.rays - list(iso.rays_per_bounce)[0]) * BYTES_SHADE_OUT
+            elif kname == "trace_kernel":
                 ims, ibytes, il = iso.ms_trace, iso.rays * BYTES_TRACE, iso.launches_trace
             else:
                 ims = iso.ms_shade
@@ -237,7 +246,7 @@ def main():
             ia = ibytes / (ims * 1e-3) / 1e9 if ims > 0 else 0.0
             isolated = {"achieved": round(ia, 2), "frac": round(ia / HBM_PEAK_GBS, 5), "avg_launch_ms": round(ims / max(1, il), 5),
                         "kernel_ms_per_step": {"raygen": round(iso.ms_raygen, 3), "trace": round(iso.ms_trace, 3),
-                                               "shade": round(iso.ms_shade, 3), "fold": round(iso.ms_fold, 3)},
+                                               "shade": round(iso.ms_shade, 3), "fold": round(iso.ms_fold, 3), "path": round(iso.ms_path, 3)},
                         "note": "one untimed frame with lanes=1 (no overlap between sub-passes)"}
         out = {
             "metric": "Mrays/s (ray segments = hit queries per second), CornellBox 1080p 256spp; ms_per_step = s/frame*1e3",
@@ -270,7 +279,7 @@ def main():
             },
             "kernel_ms_per_step": {"raygen": round(ms_raygen / args.steps, 3), "trace": round(ms_trace / args.steps, 3),
                                    "shade": round(ms_shade / args.steps, 3), "fold": round(ms_fold / args.steps, 3),
-                                   "repack": round(ms_repack / args.steps, 3)},
+                                   "repack": round(ms_repack / args.steps, 3), "path": round(ms_path / args.steps, 3)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

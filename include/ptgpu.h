@@ -124,13 +124,14 @@ typedef struct PtStats {
     uint32_t passes;          /* wavefront passes the call was split into */
     uint32_t launches_trace;  /* trace kernel launches */
     uint32_t launches_shade;
-    uint32_t reserved;
+    uint32_t launches_path;   /* fused path-kernel launches (one per sub-pass; then there are no trace / shade launches) */
     double ms_total;          /* first launch to last completion */
     double ms_raygen;
     double ms_trace;
     double ms_shade;
     double ms_fold;
     double ms_repack;
+    double ms_path;           /* the fused path kernel (trace + shade of every bounce in one launch) */
     uint64_t rays_per_bounce[64]; /* live rays entering bounce b (b >= 64 folded into the last slot) */
 } PtStats;
 
@@ -153,6 +154,9 @@ const char* pt_last_error(const PtContext* ctx);
  * "lanes" (1..4: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
  *   trace overlaps another's shade; default 2), "lane_sync" (1 = lanes advance in lock step through events; default 0
  *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid; default 1),
+ * "fused" (1 = scenes that take the lockstep walk and have only solid textures run the whole bounce loop of a sub-pass in one
+ *   launch, each wave on its own region; 0 = one trace and one shade launch per bounce; default 0 -- the fused kernel needs 87
+ *   VGPRs, runs 5 waves per SIMD instead of 8 and measures 10-15 % slower on the Cornell box; results are identical),
  * "trace_mode" (which kernel answers the hit queries, applied at the next pt_scene_upload: -1 = by scene size, 0 = wave-uniform
  *   lockstep walk, 1 = per-lane walk with an LDS stack, 2 = per-lane stackless walk of the record stream; all three give
  *   identical results),

@@ -110,13 +110,14 @@ class PtStats(C.Structure):
         ("passes", C.c_uint32),
         ("launches_trace", C.c_uint32),
         ("launches_shade", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("launches_path", C.c_uint32),
         ("ms_total", C.c_double),
         ("ms_raygen", C.c_double),
         ("ms_trace", C.c_double),
         ("ms_shade", C.c_double),
         ("ms_fold", C.c_double),
         ("ms_repack", C.c_double),
+        ("ms_path", C.c_double),
         ("rays_per_bounce", C.c_uint64 * 64),
     ]
 

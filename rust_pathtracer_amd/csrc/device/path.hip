@@ -1,0 +1,92 @@
+// path.hip -- the whole bounce loop of a pass in ONE launch, for scenes that take the wave-uniform walk.
+//
+// Wave-private regions (pt_launch.h) mean that a wave never needs anything another wave produced: its rays stay in its
+// own region through every bounce.  So the wave runs Ray::color's loop (ray.rs:20-41) by itself,
+//     for each bounce:  for each 64-ray chunk of its region:  load ray + state -> trace (lockstep walk) -> shade ->
+//                       append the survivors to the region of the other ping-pong buffer,
+// with the hit record never leaving registers.  Per ray segment this moves 64 B in and 64 B per survivor out (the
+// separate trace and shade kernels: 200 B), costs no kernel launches or grid-wide joins per bounce (a launch ends with
+// its slowest wave; with 100 launches per pass the wave slots stood empty a third of the time), and interleaves the
+// compute-heavy walk with shade's memory traffic at chunk granularity on every SIMD.
+// The per-bounce count rows are still written (ray statistics; the stand-alone kernels' format).
+//
+// MEASURED (CornellBox 1080p 256 spp, one MI355X): 169 ms/frame on one stream against 167 ms for the separate kernels on
+// one stream and 145 ms for the separate kernels on two overlapped streams.  The pass is bound by instruction issue
+// (about 2300 wave instructions per 64 rays whichever way they are packaged), and this kernel's 87 VGPRs allow only
+// 5 waves per SIMD where the walk alone runs 8.  It is therefore OFF by default (option "fused"); it stays as the
+// variant that allocates the least traffic (115 B instead of 200 B per segment) for machines where bandwidth binds.
+#include "pt_shade.h"
+
+struct PathArgs {
+    RayStream rays[2];
+    uint4* state[2];
+    uint32_t* counts; // rows of n_waves + 1 words; row 0 comes from raygen, rows 1.. must be zero on entry
+    uint32_t n_waves;
+    uint32_t max_bounces;
+    ShadeEnv env;     // stream and last_bounce are set per bounce by the kernel
+};
+
+template <bool TABLE_LDS>
+__global__ __launch_bounds__(PT_BLOCK) void path_kernel(DevScene sc, PathArgs a) {
+    __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
+    __shared__ __align__(16) uint8_t s_perlin[16];
+    __shared__ uint2 s_exchange[PT_BLOCK]; // 64 slots per wave for the cooperative sampler
+    shade_stage_tables<false, TABLE_LDS>(sc, s_table, s_perlin);
+    uint2* exchange = s_exchange + (threadIdx.x & ~63u);
+    const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t row = a.n_waves + 1u;
+    uint32_t n = __builtin_amdgcn_readfirstlane(a.counts[wave]);
+    const uint32_t region = a.counts[a.n_waves];
+    const size_t region_base = (size_t)wave * region;
+    ShadeEnv env = a.env;
+    for (uint32_t bounce = 0; bounce < a.max_bounces && n != 0u; ++bounce) {
+        env.stream = bounce + 1u;
+        env.last_bounce = bounce + 1u >= a.max_bounces;
+        const bool odd = bounce & 1u;
+        const RayStream in = odd ? a.rays[1] : a.rays[0], out = odd ? a.rays[0] : a.rays[1];
+        const uint4* state_in = odd ? a.state[1] : a.state[0];
+        uint4* state_out = odd ? a.state[0] : a.state[1];
+        uint32_t out_n = 0; // survivors this wave has written so far (wave-uniform)
+        for (uint32_t first = 0; first < n; first += 64u) {
+            const uint32_t k = first + lane;
+            const size_t i = region_base + k;
+            const bool live = k < n;
+            // idle lanes carry an ordinary ray (see trace_walk_kernel)
+            double2 ra = make_double2(0x1p40, 0x1p40), rb = make_double2(0x1p40, 1), rc = make_double2(1, 1);
+            uint4 st = make_uint4(0, 0, 0, 0);
+            if (live) {
+                ra = in.a[i];
+                rb = in.b[i];
+                rc = in.c[i];
+                st = state_in[i];
+            }
+            const V3 o = v3(ra.x, ra.y, rb.x), d = v3(rb.y, rc.x, rc.y);
+            double t;
+            int32_t prim;
+            traverse_walk(sc.walk, sc.walk_bytes, sc.walk_flags, live, o, d, 0.001, __builtin_huge_val(), t, prim); // ray.rs:25
+            bool alive;
+            V3 next_o, next_d;
+            shade_chunk<false, TABLE_LDS>(sc, env, s_table, s_perlin, false, exchange, live, st, o, d, t, prim, alive, next_o, next_d);
+            if (!env.last_bounce) out_n += append_survivors(alive, out, state_out, region_base, out_n, next_o, next_d, st);
+        }
+        if (lane == 0) a.counts[(size_t)(bounce + 1u) * row + wave] = out_n;
+        // the wave's own stores (survivors, radiance sums) before its loads of the next bounce: same CU, same L1
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        n = out_n;
+    }
+}
+
+void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf) {
+    PathArgs a;
+    a.rays[0] = wf.rays[0];
+    a.rays[1] = wf.rays[1];
+    a.state[0] = wf.state[0];
+    a.state[1] = wf.state[1];
+    a.counts = wf.counts;
+    a.n_waves = wf.n_waves;
+    a.max_bounces = p.max_bounces;
+    a.env = make_shade_env(p, wf, 0);
+    if (sc.n_prims <= PT_SHADE_LDS_MAX_PRIMS) hipLaunchKernelGGL(path_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+    else hipLaunchKernelGGL(path_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+}

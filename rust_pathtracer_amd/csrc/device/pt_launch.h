@@ -54,6 +54,10 @@ void launch_raygen(hipStream_t s, const LaunchGeom& g, const PtCamera& cam, cons
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io);
 void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf,
                   const BounceIO& io, uint32_t bounce);
+// The whole bounce loop in one launch (path.hip); the count rows 1.. of wf.counts must have been zeroed.
+void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf);
+struct ShadeEnv;
+ShadeEnv make_shade_env(const PassParams& p, const Wavefront& wf, uint32_t bounce);
 // Re-deals the rays of buffer io.in evenly over the waves into buffer io.out (counts_in -> counts_out).
 void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io);
 void launch_fold(hipStream_t s, const PassParams& p, const Wavefront& wf, uint32_t sample_slots, float* accum);

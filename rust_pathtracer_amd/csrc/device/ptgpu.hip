@@ -57,6 +57,7 @@ struct PtContext {
     int profile = 1;
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
+    int fused = 0;                // one path kernel per pass where it applies (measured: not faster, see path.hip)
     int repack_every = 0, repack_first = 8;  // measured on Cornell 1080p: the copy costs more than the fuller waves save
     std::vector<hipEvent_t> events;
 
@@ -321,6 +322,8 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
     } else if (k == "repack_first") {  // first bounce before which a repack runs
         if (value < 1 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "repack_first out of range");
         ctx->repack_first = (int)value;
+    } else if (k == "fused") {  // 1: the whole bounce loop in one launch where the lockstep walk applies; 0: a trace and a shade launch per bounce
+        ctx->fused = value ? 1 : 0;
     } else if (k == "trace_mode") {  // -1 automatic, 0 lockstep walk, 1 per-lane stack (LDS), 2 per-lane record stream; next upload
         if (value < -1 || value > 2) return ctx->fail(PT_ERR_BAD_ARG, "trace_mode out of range [-1, 2]");
         ctx->trace_mode_override = (int)value;
@@ -729,7 +732,9 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
 
     // Event bookkeeping.  Every launch is bracketed by two events on its own stream; the stop event doubles as the
     // hand-off the other lane waits on.
-    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5 };
+    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5, K_PATH = 6 };
+    // one launch for the whole bounce loop (path.hip) where the wave-uniform walk applies and textures are solid
+    const bool fused = ctx->fused && ctx->sc.trace_mode == PT_TRACE_LOCKSTEP && !ctx->sc.has_procedural && ctx->repack_every == 0;
     struct Timed { int kind; size_t start, stop; };
     std::vector<Timed> timed;
     size_t ev_used = 0;
@@ -757,7 +762,8 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         pl.steps.push_back({K_RAYGEN, 0, BounceIO{0, 1, nullptr, nullptr}});
         int buf = 0;
         const uint32_t* counts_in = wf.counts;
-        for (uint32_t b = 0; b < max_bounces; ++b) {
+        if (fused) pl.steps.push_back({K_PATH, 0, BounceIO{0, 1, nullptr, nullptr}});
+        for (uint32_t b = 0; b < max_bounces && !fused; ++b) {
             BounceIO io{buf, buf ^ 1, counts_in, wf.counts + count_row(wf, b + 1)};
             pl.steps.push_back({K_TRACE, b, io});
             pl.steps.push_back({K_SHADE, b, io});
@@ -782,7 +788,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     PT_HIP(ctx, hipEventRecord(ctx->events[ev_begin], ctx->stream));
     for (int l = 1; l < n_lanes; ++l) PT_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->events[ev_begin], 0));
 
-    uint32_t passes = 0, launches_trace = 0, launches_shade = 0;
+    uint32_t passes = 0, launches_trace = 0, launches_shade = 0, launches_path = 0;
     long fold_guard = -1;  // stop event of the last fold: folds add to the same buffer and must not overlap
     for (uint32_t done = 0; done < sample_count; done += slots) {
         const uint32_t cur = std::min(slots, sample_count - done);
@@ -819,7 +825,12 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                 PT_HIP(ctx, new_event(t.stop));
                 PT_HIP(ctx, hipEventRecord(ctx->events[t.start], ln.stream));
                 switch (st.kind) {
-                    case K_RAYGEN: launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf); break;
+                    case K_RAYGEN:
+                        if (fused)  // waves that run out of rays leave the rest of their count column untouched
+                            PT_HIP(ctx, hipMemsetAsync(ln.wf.counts, 0, (size_t)n_counts * (ln.wf.n_waves + 1u) * sizeof(uint32_t), ln.stream));
+                        launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf);
+                        break;
+                    case K_PATH: launch_path(ln.stream, geom, ctx->sc, plan[l].p, ln.wf); ++launches_path; break;
                     case K_TRACE: launch_trace(ln.stream, geom, ctx->sc, ln.wf, st.io); ++launches_trace; break;
                     case K_SHADE: launch_shade(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_shade; break;
                     case K_REPACK: launch_repack(ln.stream, geom, ln.wf, st.io); break;
@@ -857,6 +868,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         stats->passes = passes;
         stats->launches_trace = launches_trace;
         stats->launches_shade = launches_shade;
+        stats->launches_path = launches_path;
         for (uint32_t b = 0; b < max_bounces; ++b) {
             unsigned long long v = 0;
             for (int l = 0; l < n_lanes; ++l) v += totals[(size_t)l * n_counts + b];
@@ -875,6 +887,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_SHADE: stats->ms_shade += ms; break;
                     case K_FOLD: stats->ms_fold += ms; break;
                     case K_REPACK: stats->ms_repack += ms; break;
+                    case K_PATH: stats->ms_path += ms; break;
                     default: break;
                 }
             }

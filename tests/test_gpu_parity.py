@@ -331,7 +331,7 @@ def test_render_is_deterministic_and_pass_invariant(gpu_ctx, pt):
 
 
 def test_scheduling_options_do_not_change_results(gpu_ctx, pt, oracle):
-    # lanes (overlapped sub-passes), repack (re-dealing survivors over the waves) and the persistent-grid size only
+    # lanes (overlapped sub-passes), repack (re-dealing survivors over the waves), the fused path kernel and the persistent-grid size only
     # change WHERE and WHEN a path is computed: hit-query counts stay exact, images agree to the f32 fold order
     w, h, spp, depth, seed = 72, 40, 9, 40, 8
     ctx = pt.Context(0)
@@ -339,9 +339,10 @@ def test_scheduling_options_do_not_change_results(gpu_ctx, pt, oracle):
         results = []
         for opts in [dict(lanes=1), dict(lanes=2), dict(lanes=4), dict(lanes=2, lane_sync=1, lane_full_grid=0),
                      dict(lanes=1, repack_every=1, repack_first=1), dict(lanes=3, repack_every=3, repack_first=2, blocks_per_cu=3),
-                     dict(lanes=2, paths_per_pass=w * h * 4)]:
+                     dict(lanes=2, paths_per_pass=w * h * 4), dict(lanes=1, fused=1), dict(lanes=2, fused=1, blocks_per_cu=5),
+                     dict(lanes=2, fused=1, paths_per_pass=w * h * 2)]:
             defaults = dict(lanes=2, lane_sync=0, lane_full_grid=1, repack_every=0, repack_first=8, blocks_per_cu=0,
-                            paths_per_pass=1 << 27)
+                            paths_per_pass=1 << 27, fused=0)
             for k, v in {**defaults, **opts}.items():
                 ctx.set_option(k, v)
             s, o = su.named_pair("CornellBox", 1, 1, 1, image=(w, h, spp, depth, (0, 0, 0)))
