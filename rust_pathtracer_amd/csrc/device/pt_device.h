@@ -245,7 +245,7 @@ struct ShadePrim {
     double pad1;
 };
 static_assert(sizeof(ShadePrim) == 80, "ShadePrim must be 80 bytes");
-#define PT_SHADE_LDS_MAX_PRIMS 256
+#define PT_SHADE_LDS_MAX_PRIMS 192
 
 struct DevScene {
     const DevNode* nodes;
