@@ -100,6 +100,15 @@ void pth_camera_new(const double lookfrom[3], const double lookat[3], const doub
  * GPU `device`: rgb_out = width*height*3 bytes, top row first.  stats may be NULL. */
 int pth_render(PthScene* s, int device, double t, uint64_t seed, uint8_t* rgb_out, PtStats* stats);
 
+/* write_file (main.rs:78-91): an 8-bit RGB PNG, rows top first. */
+int pth_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb);
+/* The frame loop of main.rs:24-72 for frames first_frame, first_frame + frame_stride, ... (< the scene's frame count =
+ * fps * duration, or 1 for a static image; at most max_frames of them when max_frames > 0): frame i is rendered at t = i / count
+ * with the scene's ImageSettings and written to out_dir/image_{i:04}.png (the directory must exist), the PNG being encoded
+ * while the next frame renders.  A rank of an N-GPU job passes first_frame = rank, frame_stride = N.  Outputs may be NULL. */
+int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_dir, uint32_t first_frame, uint32_t frame_stride,
+                      uint32_t max_frames, uint32_t* frames_total, uint32_t* frames_written, double* seconds_render, double* seconds_write,
+                      uint64_t* rays);
 /* OBJ reader probe: number of models / triangles / materials the reader finds in a file (-1 on error). */
 int pth_obj_probe(const char* path, uint32_t* n_models, uint64_t* n_triangles, uint32_t* n_materials);
 

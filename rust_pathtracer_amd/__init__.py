@@ -22,6 +22,7 @@ from .api import (  # noqa: F401
     PtError,
     Scene,
     camera_new,
+    write_png,
     device_count,
     libptgpu,
     libpthost,

@@ -213,6 +213,9 @@ _PTHOST_PROTOS = {
          C.POINTER(PtCamera)],
     ),
     "pth_render": (C.c_int, [_vp, C.c_int, C.c_double, C.c_uint64, _vp, C.POINTER(PtStats)]),
+    "pth_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _vp]),
+    "pth_render_frames": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "pth_obj_probe": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
 }
 for _name, (_res, _args) in _PTGPU_PROTOS.items():
@@ -235,6 +238,14 @@ def device_count() -> int:
     if n < 0:
         raise PtError(libptgpu.pt_last_error(None).decode())
     return n
+
+
+def write_png(path: str, rgb: np.ndarray):
+    """write_file (main.rs:78-91): uint8 [h, w, 3] -> 8-bit RGB PNG."""
+    a = np.ascontiguousarray(rgb, dtype=np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 3
+    if libpthost.pth_write_png(os.fsencode(path), a.shape[1], a.shape[0], a.ctypes.data) != 0:
+        raise PtError(libpthost.pth_last_error().decode())
 
 
 def camera_new(lookfrom, lookat, up, vertical_fov, aspect_ratio, aperture, focus_dist) -> PtCamera:
@@ -330,6 +341,16 @@ class Scene:
         stats = PtStats()
         self._ok(libpthost.pth_render(self._h, device, t, seed, out.ctypes.data, C.byref(stats)))
         return out, stats
+
+    def render_frames(self, out_dir: str, device: int = 0, seed: int = 0, first_frame: int = 0, frame_stride: int = 1, max_frames: int = 0):
+        """The frame loop of main.rs:24-72: renders the scene's frames (one for a static image) and writes
+        out_dir/image_%04d.png, encoding each PNG while the next frame renders."""
+        total, written, rays = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        t_render, t_write = C.c_double(), C.c_double()
+        self._ok(libpthost.pth_render_frames(self._h, device, seed, os.fsencode(out_dir), first_frame, frame_stride, max_frames,
+                                             C.byref(total), C.byref(written), C.byref(t_render), C.byref(t_write), C.byref(rays)))
+        return {"frames_total": total.value, "frames_written": written.value, "seconds_render": t_render.value,
+                "seconds_write": t_write.value, "rays": rays.value}
 
     # flattened tables as numpy views (copies), for tests
     def nodes_array(self) -> np.ndarray:

@@ -1,8 +1,12 @@
 // capi.cpp -- the C view of the host layer declared in include/pthost.h.
 #include "pthost.h"
 
+#include <chrono>
 #include <map>
+#include <string>
+#include <thread>
 
+#include "output.hpp"
 #include "renderer.hpp"
 
 using namespace pt;
@@ -293,6 +297,70 @@ int pth_render(PthScene* s, int device, double t, uint64_t seed, uint8_t* rgb_ou
         std::vector<uint8_t> px = r->render(s->scene->get_camera_at(t), im.width, im.height, im.background, im.samples_per_pixel,
                                             im.max_bounces, seed, stats);
         std::memcpy(rgb_out, px.data(), px.size());
+    });
+}
+
+int pth_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    return guarded([&] {
+        if (!path || !rgb) throw std::runtime_error("pth_write_png: null argument");
+        write_file(path, width, height, rgb, (size_t)width * height * 3);
+    });
+}
+
+// main.rs:24-72: the frame loop.  Frame i of N is rendered at t = i/N and written to out_dir/image_{i:04}.png; the PNG of
+// frame i is encoded and written by a second thread while frame i + stride renders.
+int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_dir, uint32_t first_frame, uint32_t frame_stride,
+                      uint32_t max_frames, uint32_t* frames_total, uint32_t* frames_written, double* seconds_render, double* seconds_write,
+                      uint64_t* rays) {
+    return guarded([&] {
+        if (!s || !out_dir) throw std::runtime_error("pth_render_frames: null argument");
+        if (!s->built) throw std::runtime_error("pth_render_frames: scene not built");
+        if (frame_stride == 0) throw std::runtime_error("pth_render_frames: frame_stride must be at least 1");
+        auto& r = s->renderers[device];
+        if (!r) r.reset(new GpuRenderer(device));
+        if (!s->uploaded[device]) {
+            r->upload(*s->world);
+            s->uploaded[device] = true;
+        }
+        const OutputSettings o = s->scene->get_output_settings();
+        const ImageSettings& im = o.image_settings;
+        const uint64_t amount_of_frames = o.animation ? (uint64_t)(o.fps * o.duration) : 1;  // main.rs:25-32
+        if (frames_total) *frames_total = (uint32_t)amount_of_frames;
+        std::thread writer;
+        std::string write_error;
+        double t_render = 0.0, t_write = 0.0;
+        uint32_t written = 0;
+        uint64_t ray_sum = 0;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        for (uint64_t frame_index = first_frame; frame_index < amount_of_frames && written < (max_frames ? max_frames : 0xFFFFFFFFu);
+             frame_index += frame_stride) {
+            const double t = (double)frame_index / (double)amount_of_frames;  // main.rs:52
+            PtStats st;
+            const double t0 = now();
+            std::vector<uint8_t> pixels = r->render(s->scene->get_camera_at(t), im.width, im.height, im.background,
+                                                    im.samples_per_pixel, im.max_bounces, seed, &st);
+            t_render += now() - t0;
+            ray_sum += st.rays;
+            if (writer.joinable()) writer.join();
+            if (!write_error.empty()) throw std::runtime_error(write_error);
+            const std::string path = frame_path(out_dir, (size_t)frame_index);
+            writer = std::thread([&write_error, &t_write, now, path, w = im.width, h = im.height, px = std::move(pixels)] {
+                const double w0 = now();
+                try {
+                    write_file(path, w, h, px);
+                } catch (const std::exception& e) {
+                    write_error = e.what();
+                }
+                t_write += now() - w0;
+            });
+            ++written;
+        }
+        if (writer.joinable()) writer.join();
+        if (!write_error.empty()) throw std::runtime_error(write_error);
+        if (frames_written) *frames_written = written;
+        if (seconds_render) *seconds_render = t_render;
+        if (seconds_write) *seconds_write = t_write;
+        if (rays) *rays = ray_sum;
     });
 }
 

@@ -406,6 +406,36 @@ def test_converged_image_with_independent_seeds(gpu_ctx, oracle):
         assert abs(img.astype(float).mean() - ref.astype(float).mean()) / 255.0 < 0.002  # no bias
 
 
+def test_frame_loop_writes_the_frames_render_returns(pt, tmp_path):
+    """main.rs:24-72 through pth_render_frames and through the ptrender executable: frame i of N is render(t = i/N),
+    written as image_%04d.png."""
+    import subprocess
+    from test_host import read_png
+
+    s = pt.Scene("SphereField").set_seeds(3, 3, 3).set_image(64, 36, 4, 8, (1, 1, 1)).build()
+    st = s.settings()
+    assert st["animation"] and st["fps"] * st["duration"] == 300
+    info = s.render_frames(str(tmp_path), seed=3, first_frame=1, frame_stride=150, max_frames=0)
+    assert info["frames_total"] == 300 and info["frames_written"] == 2 and info["rays"] > 0
+    for i in (1, 151):
+        img, _ = s.render(0, i / 300.0, seed=3)
+        assert np.array_equal(read_png(str(tmp_path / f"image_{i:04d}.png")), img)
+    # a static image has one frame
+    c = pt.Scene("CornellBox").set_seeds(3, 3, 3).set_image(40, 30, 3, 6, (0, 0, 0)).build()
+    info = c.render_frames(str(tmp_path / "."), seed=3)
+    assert info["frames_total"] == 1 and info["frames_written"] == 1
+    want, _ = c.render(0, 0.0, seed=3)
+    assert np.array_equal(read_png(str(tmp_path / "image_0000.png")), want)
+    # the executable
+    exe = os.path.join(os.path.dirname(api.__file__), "bin", "ptrender")
+    out = tmp_path / "cli"
+    r = subprocess.run([exe, "CornellBox", "--width", "40", "--height", "30", "--spp", "3", "--depth", "6", "--seed", "3", "--out", str(out)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_png(str(out / "image_0000.png")), want)
+    assert subprocess.run([exe, "NoSuchScene"], capture_output=True, timeout=60).returncode != 0
+
+
 def test_external_accumulation_buffer(gpu_ctx, pt):
     torch = pytest.importorskip("torch")
     w, h, spp, depth = 32, 24, 3, 10

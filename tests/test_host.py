@@ -246,3 +246,39 @@ def test_sharding_rules(pt):
     assert sorted(sum((pt.frames_for_rank(120, r, 8) for r in range(8)), [])) == list(range(120))
     with pytest.raises(ValueError):
         pt.sample_range_for_rank(8, 2, 2)
+
+
+def read_png(path):
+    """Minimal decoder for what write_file produces: 8-bit RGB, filter 0, one or more IDAT chunks."""
+    import struct
+    import zlib
+
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(kind + body) == crc
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks][0] == b"IHDR" and chunks[-1] == (b"IEND", b"")
+    w, h, depth, colour, comp, filt, interlace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, filt, interlace) == (8, 2, 0, 0, 0)  # png::ColorType::Rgb, main.rs:87
+    raw = zlib.decompress(b"".join(b for k, b in chunks if k == b"IDAT"))
+    rows = np.frombuffer(raw, np.uint8).reshape(h, w * 3 + 1)
+    assert not rows[:, 0].any()
+    return rows[:, 1:].reshape(h, w, 3)
+
+
+def test_png_writer_round_trip(pt, tmp_path):
+    # main.rs:78-91: 8-bit RGB, rows top first
+    rng = np.random.default_rng(4)
+    for w, h in [(1, 1), (7, 3), (400, 225)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        path = str(tmp_path / f"a_{w}x{h}.png")
+        pt.write_png(path, img)
+        assert np.array_equal(read_png(path), img)
+    with pytest.raises(pt.PtError, match="could not create image file"):
+        pt.write_png(str(tmp_path / "no_such_dir" / "a.png"), np.zeros((2, 2, 3), np.uint8))
