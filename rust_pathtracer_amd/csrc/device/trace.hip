@@ -80,6 +80,9 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const unsigned cha
 #ifndef PT_REFILL_LANES
 #define PT_REFILL_LANES 16
 #endif
+#ifndef PT_NODE_STEPS
+#define PT_NODE_STEPS 4
+#endif
 #ifndef PT_LEAF_LANES
 #define PT_LEAF_LANES 24
 #endif
@@ -115,7 +118,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
         const unsigned long long at_node = __builtin_amdgcn_ballot_w64(busy && w.at_node());
         const unsigned long long at_leaf = __builtin_amdgcn_ballot_w64(busy && !w.at_node());
         if (at_node != 0ull && (uint32_t)__builtin_popcountll(at_leaf) < PT_LEAF_LANES) {
-            if (busy && w.at_node()) w.step_node(stream);
+            // a few box tests per round: the bookkeeping above costs as much as one of them
+#pragma unroll
+            for (int r = 0; r < PT_NODE_STEPS; ++r)
+                if (busy && w.at_node() && w.off < stream_bytes) w.step_node(stream);
         } else {
             if (busy && !w.at_node()) w.step_leaf(stream);
         }
