@@ -147,12 +147,12 @@ void pt_context_destroy(PtContext* ctx);
 /* Message of the last failing call on ctx (or of the last failing pt_context_create when ctx is NULL). */
 const char* pt_last_error(const PtContext* ctx);
 
-/* Options: "paths_per_pass" (upper bound on paths in flight, 156 B each; default 128 Mi),
+/* Options: "paths_per_pass" (upper bound on paths in flight, 156 B each; default 512 Mi = 84 GB, halved until the streams fit the device),
  * "profile" (1 = time every kernel with HIP events and fill PtStats.ms_*; default 1),
  * "repack_every" / "repack_first" (re-deal surviving rays over the waves every N bounces from bounce F on;
  *   default 0 = never / 8),
- * "lanes" (1..4: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
- *   trace overlaps another's shade; default 2), "lane_sync" (1 = lanes advance in lock step through events; default 0
+ * "lanes" (1..8: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
+ *   trace overlaps another's shade; default 4), "lane_sync" (1 = lanes advance in lock step through events; default 0
  *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid; default 1),
  * "fused" (1 = scenes that take the lockstep walk and have only solid textures run the whole bounce loop of a sub-pass in one
  *   launch, each wave on its own region; 0 = one trace and one shade launch per bounce; default 0 -- the fused kernel needs 87

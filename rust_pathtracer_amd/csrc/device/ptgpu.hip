@@ -7,7 +7,7 @@
 
 #include "pt_launch.h"
 
-#define PT_MAX_LANES 4
+#define PT_MAX_LANES 8
 
 namespace {
 thread_local std::string g_last_error;
@@ -48,12 +48,12 @@ struct PtContext {
         std::vector<DevBuf> bufs;
     };
     Lane lanes[PT_MAX_LANES];
-    int n_lanes = 2;
+    int n_lanes = 4;
     int lane_sync = 0;
     int lane_full_grid = 1;
 
     // options
-    int64_t paths_per_pass = (int64_t)1 << 27;
+    int64_t paths_per_pass = (int64_t)1 << 29;
     int profile = 1;
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
@@ -310,7 +310,7 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
     } else if (k == "profile") {
         ctx->profile = value ? 1 : 0;
     } else if (k == "lanes") {  // 2: two half-size sub-passes on two streams, trace of one overlapping shade of the other; 1: serial
-        if (value < 1 || value > PT_MAX_LANES) return ctx->fail(PT_ERR_BAD_ARG, "lanes must be 1..4");
+        if (value < 1 || value > PT_MAX_LANES) return ctx->fail(PT_ERR_BAD_ARG, "lanes must be 1..8");
         ctx->n_lanes = (int)value;
     } else if (k == "lane_sync") {  // 1: a lane's step waits for the other lane's previous step (lock-step pairing); 0: free-running
         ctx->lane_sync = value ? 1 : 0;
@@ -707,18 +707,26 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     uint64_t slots64 = std::max<uint64_t>(1, (uint64_t)ctx->paths_per_pass / npix);
     slots64 = std::min<uint64_t>(slots64, sample_count);
     slots64 = std::min<uint64_t>(slots64, 0xFFFFFFFFull / npix);
-    const uint32_t slots = (uint32_t)slots64;
+    uint32_t slots = (uint32_t)slots64;
     const uint32_t n_counts = max_bounces + 1;
     // Lanes share a pass: the pass's sample slots are dealt out to up to n_lanes independent sub-passes, each on its
     // own stream with its own buffers, started one pipeline step apart and then free-running, so that the VALU-bound
     // trace of one lane shares the machine with the memory-bound shade of another.
-    const int n_lanes = (int)std::min<uint32_t>((uint32_t)ctx->n_lanes, slots);
+    int n_lanes = 1;
     LaunchGeom geom = ctx->geom;
-    if (n_lanes > 1 && !ctx->lane_full_grid) geom.grid = std::max<uint32_t>(1u, ctx->geom.grid / (uint32_t)n_lanes);
     auto lane_share = [](uint32_t total, int lanes, int l) { return total / (uint32_t)lanes + ((uint32_t)l < total % (uint32_t)lanes ? 1u : 0u); };
-    for (int l = 0; l < n_lanes; ++l) {
-        int rc = ensure_lane(ctx, ctx->lanes[l], geom.grid, (size_t)lane_share(slots, n_lanes, l) * npix, max_bounces);
-        if (rc != PT_OK) return rc;
+    for (;;) {  // a pass as large as allowed; when the device cannot hold its streams, half as large
+        n_lanes = (int)std::min<uint32_t>((uint32_t)ctx->n_lanes, slots);
+        geom = ctx->geom;
+        if (n_lanes > 1 && !ctx->lane_full_grid) geom.grid = std::max<uint32_t>(1u, ctx->geom.grid / (uint32_t)n_lanes);
+        int rc = PT_OK;
+        for (int l = 0; l < n_lanes && rc == PT_OK; ++l)
+            rc = ensure_lane(ctx, ctx->lanes[l], geom.grid, (size_t)lane_share(slots, n_lanes, l) * npix, max_bounces);
+        if (rc == PT_OK) break;
+        free_wavefront(ctx);
+        (void)hipGetLastError();
+        if (slots == 1) return rc;
+        slots = (slots + 1) / 2;
     }
 
     PassParams base{};
