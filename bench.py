@@ -197,7 +197,7 @@ def main():
     if world == 1 and not args.lanes:
         ctx.set_option("lanes", 1)
         iso, _ = step()
-        ctx.set_option("lanes", 4)  # the library default
+        ctx.set_option("lanes", 0)  # the library default (automatic)
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
