@@ -222,6 +222,10 @@ static_assert(sizeof(DevPrim) == 80, "DevPrim must be 80 bytes");
 //   PT_WK_SPHERE    payload center, radius (4)             aux = primitive index
 //   PT_WK_TRIANGLE  payload point1, edge1, edge2 (9)       aux = primitive index
 enum { PT_WK_NODE = 0, PT_WK_RECT_XY = 1, PT_WK_RECT_XZ = 2, PT_WK_RECT_YZ = 3, PT_WK_BOX6 = 4, PT_WK_SPHERE = 5, PT_WK_TRIANGLE = 6 };
+// Streams built for the ordered walk also carry, in a primitive record's kind word above PT_WK_LINK_SHIFT, the offset
+// (in 8-byte words) of the node record that is its parent in the reference's tree.
+#define PT_WK_KIND_MASK 7u
+#define PT_WK_LINK_SHIFT 3
 #define PT_WK_NODE_BYTES 56u
 #define PT_WK_RECT_BYTES 48u
 #define PT_WK_BOX6_BYTES 56u
@@ -229,7 +233,8 @@ enum { PT_WK_NODE = 0, PT_WK_RECT_XY = 1, PT_WK_RECT_XZ = 2, PT_WK_RECT_YZ = 3, 
 #define PT_WK_TRIANGLE_BYTES 80u
 #define PT_WALK_MAX_ITEMS 192 /* nodes + primitives: the stream stays within the scalar cache */
 #define PT_WALK_PLANES_IN_RANGE 1u /* walk_flags: see walk_division_is_proven */
-enum { PT_TRACE_LOCKSTEP = 0, PT_TRACE_STACK = 1, PT_TRACE_STREAM = 2 };
+#define PT_WALK_BOXES_NESTED 2u    /* every node's box is finite and contains its child nodes' boxes (OrderedWalk) */
+enum { PT_TRACE_LOCKSTEP = 0, PT_TRACE_STACK = 1, PT_TRACE_STREAM = 2, PT_TRACE_ORDERED = 3 };
 // Everything shade needs about the primitive it hit, in ONE 80-byte record (one dependent fetch instead of the
 // chain primitive -> material -> texture): the geometry the normal comes from, the material, and the colour
 // when the material's texture is a solid one.
@@ -266,6 +271,8 @@ struct DevScene {
     uint32_t walk_flags; // PT_WALK_*
     uint32_t has_procedural; // any checker / marble texture
     const ShadePrim* shade_prims;
+    const unsigned char* guide; // the guide tree of the ordered walk (guide_tree.h), node 0 = root; null when there is none
+    uint32_t guide_nodes;
 };
 
 // ------------------------------------------------------------------ hit tests (t only; the record is rebuilt in shade)
@@ -681,14 +688,25 @@ struct StreamWalk {
     uint32_t off;      // byte offset of the current record
     uint32_t kind, aux; // its header
     double g[6];       // and the first 48 bytes of its payload
+#ifdef PT_DEBUG_BOUNDS
+    uint32_t lim = 0xFFFFFFFFu;
+#endif
 #ifdef PT_DEBUG_STEPS
     uint32_t steps_nodes, steps_leaves;
 #endif
-    __device__ __forceinline__ void fetch(const unsigned char* __restrict__ stream) {
+    // (`limit`: callers that want a fetch outside the stream to be impossible whatever the stream holds pass its size)
+    __device__ __forceinline__ void fetch(const unsigned char* __restrict__ stream, uint32_t limit = 0xFFFFFFFFu) {
+#ifdef PT_DEBUG_BOUNDS
+        if (off > lim) {
+            printf("StreamWalk: off %u past the end %u (previous kind %u aux %u)\n", off, lim, kind, aux);
+            off = lim;
+        }
+#endif
+        off = min(off, limit);
         const uint2 hdr = *reinterpret_cast<const uint2*>(stream + off);
         const double2* q = reinterpret_cast<const double2*>(stream + off + 8u);
         const double2 a = q[0], b = q[1], c = q[2]; // within the stream's padding for the last record (and past the end: zeros)
-        kind = hdr.x; aux = hdr.y;
+        kind = hdr.x & PT_WK_KIND_MASK; aux = hdr.y; // (the rest of the word: PT_WK_LINK_SHIFT)
         g[0] = a.x; g[1] = a.y; g[2] = b.x; g[3] = b.y; g[4] = c.x; g[5] = c.y;
     }
     __device__ __forceinline__ void begin(const unsigned char* __restrict__ stream, V3 o_, V3 d_, double t_min_, double t_max_) {
@@ -707,7 +725,7 @@ struct StreamWalk {
         if (hit) { best_t = t; best_prim = (int32_t)prim; }
     }
     // the current record is a node: bvh.rs:108-110 (straight-line box test: no divergent early returns)
-    __device__ __forceinline__ void step_node(const unsigned char* __restrict__ stream) {
+    __device__ __forceinline__ void step_node(const unsigned char* __restrict__ stream, uint32_t limit = 0xFFFFFFFFu) {
 #ifdef PT_DEBUG_STEPS
         steps_nodes += 1;
 #endif
@@ -722,10 +740,10 @@ struct StreamWalk {
         lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
         miss |= hi <= lo;
         off = miss ? aux : off + PT_WK_NODE_BYTES;
-        fetch(stream);
+        fetch(stream, limit);
     }
     // the current record is a primitive (or the six sides of a box)
-    __device__ __forceinline__ void step_leaf(const unsigned char* __restrict__ stream) {
+    __device__ __forceinline__ void step_leaf(const unsigned char* __restrict__ stream, uint32_t limit = 0xFFFFFFFFu) {
 #ifdef PT_DEBUG_STEPS
         steps_leaves += 1;
 #endif
@@ -757,13 +775,240 @@ struct StreamWalk {
             accept(h, t, aux);
             off += PT_WK_RECT_BYTES;
         }
-        fetch(stream);
+        fetch(stream, limit);
     }
     __device__ __forceinline__ double result_t() const {
 #ifdef PT_DEBUG_STEPS
         return (double)steps_nodes + 1e-4 * (double)steps_leaves; // debugging aid: step counts instead of t
 #else
         return best_t;
+#endif
+    }
+};
+
+// ------------------------------------------------------------------ the ordered walk (larger scenes)
+// The literal walk visits ~40 records per ray in SphereField and ~180 per ray that reaches a million-triangle mesh: the
+// reference's tree (random axis, median split, always left first) culls poorly.  Its RESULT, though, is almost always
+// "the nearest primitive"; the tree only matters when two primitives are equally near, or when one of its boxes rejects
+// a ray that still hits something inside (rounding at a box face).  The ordered walk separates the two questions:
+//   1. GUIDE/LEAF: a nearest-first traversal of the guide tree (guide_tree.h: surface-area splits, children's boxes in
+//      the parent, padded far beyond rounding) with the SAME primitive tests finds the nearest hit (P, t*) and
+//      `second_t`, the nearest among all the other candidates; subtrees are culled against near(best) = best * (1+1e-9),
+//      so every primitive whose test reports t <= near(t*) has been tested.  No hit at all => the reference misses too
+//      (it tests a subset of the primitives with the same arithmetic).
+//   2. second_t <= near(t*) (a tie or a near tie: the order of the reference's walk may decide) => LITERAL.
+//   3. VERIFY: otherwise repeat the reference's slab test (bvh.rs:18-35) on the box of P's parent node in the
+//      reference's tree, with the bound b' = min(near(t*), t_max).  (a) The reference's own bound, whenever it tests an
+//      ancestor of P, is the caller's t_max or a hit other than P, all of which are farther than near(t*); the slab
+//      test is monotone in its bound, so passing with b' means passing there.  (b) The boxes are nested (a node's box
+//      is the union of its children's, bvh.rs:37-46; checked at upload: PT_WALK_BOXES_NESTED) and every operation of
+//      the slab test is monotone -- (min - o) * inv rounds monotonically, fmax/fmin are monotone, no NaN can arise
+//      for a finite ray with nonzero direction and finite boxes -- so entry(parent) <= entry(child) and exit(parent)
+//      >= exit(child) hold IN floating point: a ray that passes a node's box with bound b' passes every ancestor's.
+//      So the reference reaches P, accepts it (t* <= its bound), and nothing it tests afterwards is accepted (no
+//      other t <= t*): it returns (P, t*).  A failed box => LITERAL.
+//   4. LITERAL: the per-lane literal walk (StreamWalk) from scratch -- also for rays with a zero or non-finite
+//      component and when the guide stack overflows.
+// Correctness never rests on the guide tree being good, only on its boxes containing their primitives.
+#define PT_GUIDE_LEAF 0x80000000u
+#define PT_GUIDE_STACK 24
+enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4 };
+struct OrderedScene { // wave-uniform: what the ordered walk reads
+    const unsigned char* guide;  // guide tree: guide_nodes records of 64 bytes, node 0 = root
+    const unsigned char* stream; // record stream with parent links, padded by 128 bytes
+    uint32_t guide_nodes, stream_bytes;
+};
+struct OrderedWalk {
+    StreamWalk w;     // the ray, t_min, the best hit so far, and the fetched 56 bytes (kind, aux, g[6])
+    uint2 tail;       // bytes 56..63 of the fetch (triangle: the 7th double)
+    double t_max;     // the caller's bound (for LITERAL)
+    double second_t;  // nearest candidate other than the best one
+    uint32_t best_parent; // stream offset of the node that is the best primitive's parent in the reference's tree
+    uint32_t cur;         // LEAF: stream offset of the fetched record
+    uint32_t mode, sp;
+#ifdef PT_DEBUG_STEPS
+    uint32_t steps_guide, steps_leaf, steps_verify, went_literal;
+#endif
+    static __device__ __forceinline__ double near(double b) { return fma(fabs(b), 1e-9, b); }
+    __device__ __forceinline__ void fetch64(const unsigned char* __restrict__ p) {
+        const uint2 hdr = *reinterpret_cast<const uint2*>(p);
+        const double2* q = reinterpret_cast<const double2*>(p + 8u);
+        const double2 a = q[0], b = q[1], c = q[2];
+        tail = *reinterpret_cast<const uint2*>(p + 56u);
+        w.kind = hdr.x; w.aux = hdr.y;
+        w.g[0] = a.x; w.g[1] = a.y; w.g[2] = b.x; w.g[3] = b.y; w.g[4] = c.x; w.g[5] = c.y;
+    }
+    // Where the lane goes next, and ONE fetch for it (the four destinations differ only in an address):
+    //   `ref` if `have`, else the top of the stack, else -- the guide traversal is over -- nowhere (nothing was hit:
+    //   the reference misses as well), the literal walk (a tie, or `literal` forced), or P's parent box.
+    __device__ __forceinline__ void advance(const OrderedScene& sc, const uint32_t* stack, bool have, uint32_t ref, bool literal) {
+        if (!have && !literal && sp > 0) {
+            sp -= 1;
+            ref = stack[sp * PT_BLOCK];
+            have = true;
+        }
+        uint32_t off; // of the record in the stream, or the node index in the guide tree
+        if (have) {
+            const bool leaf = (ref & PT_GUIDE_LEAF) != 0u;
+            off = ref & ~PT_GUIDE_LEAF;
+            mode = leaf ? PT_OW_LEAF : PT_OW_GUIDE;
+            cur = leaf ? off : cur;
+        } else if (!literal && w.best_prim < 0) {
+            mode = PT_OW_IDLE;
+            off = 0;
+        } else if (literal || second_t <= near(w.best_t)) {
+            mode = PT_OW_LITERAL; // StreamWalk::begin without recomputing the reciprocals; the root record is a node (kind word 0)
+            w.best_t = t_max;
+            w.best_prim = -1;
+            w.off = 0;
+            off = 0;
+#ifdef PT_DEBUG_STEPS
+            went_literal = 1;
+#endif
+        } else {
+            mode = PT_OW_VERIFY;
+            off = best_parent;
+        }
+#ifdef PT_DEBUG_BOUNDS
+        if (mode != PT_OW_IDLE && (mode == PT_OW_GUIDE ? off >= sc.guide_nodes : off >= sc.stream_bytes)) {
+            printf("OrderedWalk: mode %u off %u out of range (guide %u stream %u) have %d literal %d sp %u\n", mode, off, sc.guide_nodes, sc.stream_bytes, (int)have, (int)literal, sp);
+            mode = PT_OW_IDLE;
+        }
+#endif
+        // (the clamps cost two instructions and make a fetch outside the tables impossible whatever the tables hold)
+        const unsigned char* p = mode == PT_OW_GUIDE ? sc.guide + (size_t)min(off, sc.guide_nodes - 1u) * 64u : sc.stream + min(off, sc.stream_bytes);
+        if (mode != PT_OW_IDLE) fetch64(p);
+    }
+    __device__ __forceinline__ void begin(const OrderedScene& sc, V3 o, V3 d, double t_min, double t_max_) {
+        w.o = o; w.d = d;
+        w.inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+        w.t_min = t_min; w.best_t = t_max_;
+        w.best_prim = -1;
+        w.off = 0;
+        t_max = t_max_;
+        second_t = __builtin_huge_val();
+        best_parent = 0; cur = 0; sp = 0;
+#ifdef PT_DEBUG_STEPS
+        w.steps_nodes = w.steps_leaves = 0;
+        steps_guide = steps_leaf = steps_verify = went_literal = 0;
+#endif
+        // the guide's slab arithmetic and the nesting argument assume finite, nonzero reciprocals and a finite origin
+        const bool ordinary = fabs(w.inv.x) <= 0x1p1000 && fabs(w.inv.y) <= 0x1p1000 && fabs(w.inv.z) <= 0x1p1000 && fabs(w.inv.x) >= 0x1p-1000 &&
+                              fabs(w.inv.y) >= 0x1p-1000 && fabs(w.inv.z) >= 0x1p-1000 && fabs(o.x) <= 0x1p1000 && fabs(o.y) <= 0x1p1000 &&
+                              fabs(o.z) <= 0x1p1000 && t_min == t_min && t_max_ == t_max_;
+        advance(sc, nullptr, ordinary, 0u, !ordinary);
+    }
+    // one child's box against the ray: entry and exit parameters, each moved outwards by 1e-9 of itself
+    __device__ __forceinline__ bool guide_slab(float lx, float ly, float lz, float hx, float hy, float hz, double bound, double& entry) const {
+        const double ax = ((double)lx - w.o.x) * w.inv.x, bx = ((double)hx - w.o.x) * w.inv.x;
+        const double ay = ((double)ly - w.o.y) * w.inv.y, by = ((double)hy - w.o.y) * w.inv.y;
+        const double az = ((double)lz - w.o.z) * w.inv.z, bz = ((double)hz - w.o.z) * w.inv.z;
+        double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+        double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+        tn = fma(fabs(tn), -1e-9, tn);
+        tf = fma(fabs(tf), 1e-9, tf);
+        entry = tn;
+        return tn <= fmin(tf, bound) && tf >= w.t_min;
+    }
+    __device__ __forceinline__ void step_guide(const OrderedScene& sc, uint32_t* stack) {
+#ifdef PT_DEBUG_STEPS
+        steps_guide += 1;
+#endif
+        const double bound = near(w.best_t);
+        float f[12];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            f[2 * k] = __int_as_float(__double2loint(w.g[k]));
+            f[2 * k + 1] = __int_as_float(__double2hiint(w.g[k]));
+        }
+        double e0, e1;
+        const bool h0 = guide_slab(f[0], f[1], f[2], f[3], f[4], f[5], bound, e0);
+        const bool h1 = guide_slab(f[6], f[7], f[8], f[9], f[10], f[11], bound, e1);
+        const uint32_t c0 = w.kind, c1 = w.aux;
+        const bool both = h0 && h1, swap = both && e1 < e0;
+        const bool overflow = both && sp >= PT_GUIDE_STACK;
+        if (both && !overflow) {
+            stack[sp * PT_BLOCK] = swap ? c0 : c1;
+            sp += 1;
+        }
+        advance(sc, stack, (h0 || h1) && !overflow, (swap || !h0) ? c1 : c0, overflow);
+    }
+    // a candidate from a primitive test run with the bound near(best)
+    __device__ __forceinline__ void consider(bool hit, double t, uint32_t prim, uint32_t link) {
+        if (!hit) return;
+        if (t < w.best_t || w.best_prim < 0) {
+            if (w.best_prim >= 0) second_t = fmin(second_t, w.best_t);
+            w.best_t = t; w.best_prim = (int32_t)prim; best_parent = link;
+        } else {
+            second_t = fmin(second_t, t);
+        }
+    }
+    __device__ __forceinline__ void step_leaf(const OrderedScene& sc, const uint32_t* stack) {
+#ifdef PT_DEBUG_STEPS
+        steps_leaf += 1;
+#endif
+        const double bound = w.best_prim < 0 ? t_max : near(w.best_t);
+        const V3 o = w.o, d = w.d;
+        const double* g = w.g;
+        const double t_min = w.t_min;
+        const uint32_t kind = w.kind & PT_WK_KIND_MASK, aux = w.aux, link = (w.kind >> PT_WK_LINK_SHIFT) * 8u;
+        double t;
+        if (kind == PT_WK_SPHERE) {
+            consider(hit_sphere(g, o, d, t_min, bound, t), t, aux, link);
+        } else if (kind == PT_WK_TRIANGLE) {
+            const double* rest = reinterpret_cast<const double*>(sc.stream + min(cur, sc.stream_bytes) + 64u);
+            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], __hiloint2double((int)tail.y, (int)tail.x), rest[0], rest[1]};
+            consider(hit_triangle(tri, o, d, t_min, bound, t), t, aux, link);
+        } else if (kind == PT_WK_BOX6) {
+            const double r0[5] = {g[2], g[0], g[3], g[1], g[4]}, r1[5] = {g[5], g[0], g[3], g[1], g[4]};
+            const double r2[5] = {g[1], g[0], g[3], g[2], g[5]}, r3[5] = {g[4], g[0], g[3], g[2], g[5]};
+            const double r4[5] = {g[0], g[1], g[4], g[2], g[5]}, r5[5] = {g[3], g[1], g[4], g[2], g[5]};
+            // the bound is not tightened between the six sides: all candidates within near(best) must be seen
+            consider(hit_rect(r0, o.z, d.z, o.x, d.x, o.y, d.y, t_min, bound, t), t, aux, link);
+            consider(hit_rect(r1, o.z, d.z, o.x, d.x, o.y, d.y, t_min, bound, t), t, aux + 1u, link);
+            consider(hit_rect(r2, o.y, d.y, o.x, d.x, o.z, d.z, t_min, bound, t), t, aux + 2u, link);
+            consider(hit_rect(r3, o.y, d.y, o.x, d.x, o.z, d.z, t_min, bound, t), t, aux + 3u, link);
+            consider(hit_rect(r4, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux + 4u, link);
+            consider(hit_rect(r5, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux + 5u, link);
+        } else if (kind == PT_WK_RECT_XY) {
+            consider(hit_rect(g, o.z, d.z, o.x, d.x, o.y, d.y, t_min, bound, t), t, aux, link);
+        } else if (kind == PT_WK_RECT_XZ) {
+            consider(hit_rect(g, o.y, d.y, o.x, d.x, o.z, d.z, t_min, bound, t), t, aux, link);
+        } else {
+            consider(hit_rect(g, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux, link);
+        }
+        advance(sc, stack, false, 0u, false);
+    }
+    __device__ __forceinline__ void step_verify(const OrderedScene& sc) {
+#ifdef PT_DEBUG_STEPS
+        steps_verify += 1;
+#endif
+        // bvh.rs:18-35 on the box of P's parent node, with a bound the reference's cannot be below
+        const V3 o = w.o, inv = w.inv;
+        const double* g = w.g;
+        double lo = w.t_min, hi = fmin(near(w.best_t), t_max);
+        double t0 = (g[0] - o.x) * inv.x, t1 = (g[3] - o.x) * inv.x;
+        lo = fmax((inv.x < 0.0) ? t1 : t0, lo); hi = fmin((inv.x < 0.0) ? t0 : t1, hi);
+        bool miss = hi <= lo;
+        t0 = (g[1] - o.y) * inv.y; t1 = (g[4] - o.y) * inv.y;
+        lo = fmax((inv.y < 0.0) ? t1 : t0, lo); hi = fmin((inv.y < 0.0) ? t0 : t1, hi);
+        miss |= hi <= lo;
+        t0 = (g[2] - o.z) * inv.z; t1 = (g[5] - o.z) * inv.z;
+        lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
+        miss |= hi <= lo;
+        if (miss || w.kind != PT_WK_NODE) advance(sc, nullptr, false, 0u, true);
+        else mode = PT_OW_IDLE; // the reference reaches P: it returns (P, best_t)
+    }
+    __device__ __forceinline__ void step_literal(const OrderedScene& sc) {
+        if (w.at_node()) w.step_node(sc.stream, sc.stream_bytes);
+        else w.step_leaf(sc.stream, sc.stream_bytes);
+        if (w.off >= sc.stream_bytes) mode = PT_OW_IDLE;
+    }
+    __device__ __forceinline__ double result_t() const {
+#ifdef PT_DEBUG_STEPS
+        return (double)steps_guide + 1e3 * (double)steps_leaf + 1e6 * (double)steps_verify + 1e9 * (double)(w.steps_nodes + w.steps_leaves) + 1e14 * (double)went_literal;
+#else
+        return w.best_t;
 #endif
     }
 };

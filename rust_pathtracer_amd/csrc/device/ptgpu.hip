@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "guide_tree.h"
 #include "pt_launch.h"
 
 #define PT_MAX_LANES 8
@@ -28,7 +29,7 @@ struct PtContext {
     // scene
     bool has_scene = false;
     DevScene sc{};
-    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin, d_walk, d_shade;
+    DevBuf d_nodes, d_prims, d_aux, d_mats, d_texs, d_perlin, d_walk, d_shade, d_guide;
     LaunchGeom geom{};
 
     // accumulation
@@ -290,6 +291,7 @@ void pt_context_destroy(PtContext* ctx) {
     free_buf(ctx->d_texs);
     free_buf(ctx->d_perlin);
     free_buf(ctx->d_walk);
+    free_buf(ctx->d_guide);
     free_buf(ctx->d_shade);
     free_buf(ctx->d_accum_own);
     free_buf(ctx->d_rgb);
@@ -324,8 +326,8 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
         ctx->repack_first = (int)value;
     } else if (k == "fused") {  // 1: the whole bounce loop in one launch where the lockstep walk applies; 0: a trace and a shade launch per bounce
         ctx->fused = value ? 1 : 0;
-    } else if (k == "trace_mode") {  // -1 automatic, 0 lockstep walk, 1 per-lane stack (LDS), 2 per-lane record stream; next upload
-        if (value < -1 || value > 2) return ctx->fail(PT_ERR_BAD_ARG, "trace_mode out of range [-1, 2]");
+    } else if (k == "trace_mode") {  // -1 automatic, 0 lockstep walk, 1 per-lane stack (LDS), 2 per-lane record stream, 3 ordered; next upload
+        if (value < -1 || value > 3) return ctx->fail(PT_ERR_BAD_ARG, "trace_mode out of range [-1, 3]");
         ctx->trace_mode_override = (int)value;
     } else if (k == "blocks_per_cu") {  // tuning knob: persistent-grid blocks (of 4 waves) per CU; takes effect at the next upload
         if (value < 0 || value > 16) return ctx->fail(PT_ERR_BAD_ARG, "blocks_per_cu out of range [0, 16]");
@@ -476,8 +478,23 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     // small scenes: the pre-order record stream of the wave-uniform walk (pt_device.h traverse_walk)
     std::vector<uint64_t> walk; // 8-byte words; a record = {kind | aux << 32} + payload doubles
     uint32_t walk_flags = PT_WALK_PLANES_IN_RANGE;
+    std::vector<GuideLeaf> guide_leaves; // one per primitive record, for the ordered walk's guide tree (guide_tree.h)
+    const bool large = (uint64_t)s->n_nodes + s->n_prims > PT_WALK_MAX_ITEMS;
+    const bool want_guide = ctx->trace_mode_override == PT_TRACE_ORDERED || (ctx->trace_mode_override < 0 && large);
+    bool boxes_nested = true;
     {
-        auto put_header = [&](uint32_t kind, uint32_t aux_word) { walk.push_back((uint64_t)kind | ((uint64_t)aux_word << 32)); };
+        auto leaf_box = [&](const double* lo, const double* hi) {
+            GuideLeaf l;
+            for (int q = 0; q < 3; ++q) { l.lo[q] = lo[q]; l.hi[q] = hi[q]; }
+            l.offset = (uint32_t)std::min<size_t>(walk.size() * 8u, 0xFFFFFFFFu);
+            guide::pad(l);
+            guide_leaves.push_back(l);
+        };
+        // (parent_word: for primitive records of a stream built for the ordered walk, where the parent node's record starts)
+        auto put_header = [&](uint32_t kind, uint32_t aux_word, uint32_t parent_word = 0) {
+            if (want_guide && parent_word >= (1u << (32 - PT_WK_LINK_SHIFT))) boxes_nested = false; // no room for the link: no ordered walk
+            walk.push_back((uint64_t)(kind | (want_guide ? parent_word << PT_WK_LINK_SHIFT : 0u)) | ((uint64_t)aux_word << 32));
+        };
         auto put = [&](double v) {
             uint64_t bits;
             std::memcpy(&bits, &v, 8);
@@ -493,6 +510,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
             Frame& fr = st.back();
             if (fr.ref & PT_REF_LEAF) {
                 const uint32_t first = fr.ref & PT_REF_INDEX_MASK, count = (fr.ref & PT_REF_GROUP6) ? 6u : 1u;
+                const uint32_t parent = st.size() >= 2 ? st[st.size() - 2].item : 0u; // the root is a node: every leaf has one
                 bool as_box = false;
                 if (count == 6u) {
                     // the six sides of an AABox as built by geometry.rs:391-446: all from one (min, max) pair
@@ -506,7 +524,9 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
                                  same(r[4 + k].d[1], y0) && same(r[4 + k].d[2], y1) && same(r[4 + k].d[3], z0) && same(r[4 + k].d[4], z1);
                     }
                     if (as_box) {
-                        put_header(PT_WK_BOX6, first);
+                        const double lo[3] = {x0, y0, z0}, hi[3] = {x1, y1, z1};
+                        leaf_box(lo, hi);
+                        put_header(PT_WK_BOX6, first, parent);
                         for (double v : {x0, y0, z0, x1, y1, z1}) {
                             put(v);
                             if (!plane_ok(v)) walk_flags = 0;
@@ -515,14 +535,33 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
                 }
                 for (uint32_t k = 0; k < count && !as_box; ++k) {
                     const DevPrim& pr = prims[first + k];
+                    {
+                        double lo[3], hi[3];
+                        if (pr.type == PT_PRIM_SPHERE) {
+                            for (int q = 0; q < 3; ++q) { lo[q] = pr.d[q] - std::fabs(pr.d[3]); hi[q] = pr.d[q] + std::fabs(pr.d[3]); }
+                        } else if (pr.type == PT_PRIM_TRIANGLE) {
+                            const double* v = s->prims[first + k].d; // the three corners
+                            for (int q = 0; q < 3; ++q) {
+                                lo[q] = std::min(v[q], std::min(v[3 + q], v[6 + q]));
+                                hi[q] = std::max(v[q], std::max(v[3 + q], v[6 + q]));
+                            }
+                        } else { // k on the normal axis, [a_lo, a_hi] x [b_lo, b_hi] on the other two in x<y<z order
+                            const int na = pr.type == PT_PRIM_RECT_XY ? 2 : (pr.type == PT_PRIM_RECT_XZ ? 1 : 0);
+                            const int aa = na == 0 ? 1 : 0, ba = na == 2 ? 1 : 2;
+                            lo[na] = hi[na] = pr.d[0];
+                            lo[aa] = pr.d[1]; hi[aa] = pr.d[2];
+                            lo[ba] = pr.d[3]; hi[ba] = pr.d[4];
+                        }
+                        leaf_box(lo, hi);
+                    }
                     if (pr.type == PT_PRIM_SPHERE) {
-                        put_header(PT_WK_SPHERE, first + k);
+                        put_header(PT_WK_SPHERE, first + k, parent);
                         for (int q = 0; q < 4; ++q) put(pr.d[q]);
                     } else if (pr.type == PT_PRIM_TRIANGLE) {
-                        put_header(PT_WK_TRIANGLE, first + k);
+                        put_header(PT_WK_TRIANGLE, first + k, parent);
                         for (int q = 0; q < 9; ++q) put(pr.d[q]);
                     } else {
-                        put_header(PT_WK_RECT_XY + (pr.type - PT_PRIM_RECT_XY), first + k);
+                        put_header(PT_WK_RECT_XY + (pr.type - PT_PRIM_RECT_XY), first + k, parent);
                         for (int q = 0; q < 5; ++q) put(pr.d[q]);
                         if (!plane_ok(pr.d[0])) walk_flags = 0;
                     }
@@ -537,7 +576,13 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
                 for (int q = 0; q < 3; ++q) put(nd.bmin[q]);
                 for (int q = 0; q < 3; ++q) put(nd.bmax[q]);
                 for (int q = 0; q < 3; ++q)
-                    if (!(std::isfinite(nd.bmin[q]) && std::isfinite(nd.bmax[q]) && nd.bmin[q] <= nd.bmax[q])) walk_flags = 0;
+                    if (!(std::isfinite(nd.bmin[q]) && std::isfinite(nd.bmax[q]) && nd.bmin[q] <= nd.bmax[q])) { walk_flags = 0; boxes_nested = false; }
+                for (uint32_t child : {nd.left, nd.right}) {
+                    if (child & PT_REF_LEAF) continue;
+                    const PtNode& c = s->nodes[child];
+                    for (int q = 0; q < 3; ++q)
+                        if (!(nd.bmin[q] <= c.bmin[q] && c.bmax[q] <= nd.bmax[q])) boxes_nested = false;
+                }
                 fr.stage = 1;
                 const uint32_t child = nd.left;
                 st.push_back({child, 0, 0});
@@ -559,10 +604,17 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     PT_HIP(ctx, hipMemcpy(ctx->d_shade.p, shade_prims.data(), shade_prims.size() * sizeof(ShadePrim), hipMemcpyHostToDevice));
     if (walk.size() * sizeof(uint64_t) >= 0xFFFFFF00ull) return ctx->fail(PT_ERR_BAD_ARG, "pt_scene_upload: scene too large (record stream over 4 GiB)");
     const size_t walk_words = walk.size();
-    for (int k = 0; k < 8; ++k) walk.push_back(0); // the per-lane walk fetches 56 bytes per record whatever its kind
+    for (int k = 0; k < 16; ++k) walk.push_back(0); // the per-lane walks fetch 64 bytes (+16 for a triangle) per record whatever its kind
     {
         PT_HIP(ctx, ensure_buf(ctx->d_walk, walk.size() * sizeof(uint64_t)));
         PT_HIP(ctx, hipMemcpy(ctx->d_walk.p, walk.data(), walk.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    std::vector<GuideNode> guide_nodes;
+    if (boxes_nested) walk_flags |= PT_WALK_BOXES_NESTED;
+    const bool has_guide = want_guide && boxes_nested && walk.size() * sizeof(uint64_t) < 0x80000000ull && guide::build(guide_leaves, guide_nodes);
+    if (has_guide) {
+        PT_HIP(ctx, ensure_buf(ctx->d_guide, guide_nodes.size() * sizeof(GuideNode)));
+        PT_HIP(ctx, hipMemcpy(ctx->d_guide.p, guide_nodes.data(), guide_nodes.size() * sizeof(GuideNode), hipMemcpyHostToDevice));
     }
     PT_HIP(ctx, ensure_buf(ctx->d_nodes, nodes.size() * sizeof(DevNode)));
     PT_HIP(ctx, ensure_buf(ctx->d_prims, prims.size() * sizeof(DevPrim)));
@@ -596,9 +648,12 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     sc.walk = (const unsigned char*)ctx->d_walk.p;
     sc.walk_bytes = (uint32_t)(walk_words * sizeof(uint64_t));
     // which kernel walks it: the wave-uniform walk while the stream fits the scalar cache, one lane per ray beyond
-    const bool small = (uint64_t)s->n_nodes + s->n_prims <= PT_WALK_MAX_ITEMS;
-    sc.trace_mode = small ? PT_TRACE_LOCKSTEP : PT_TRACE_STREAM;
+    // and, beyond that, in nearest-first order over the guide tree where one could be built
+    sc.guide = has_guide ? (const unsigned char*)ctx->d_guide.p : nullptr;
+    sc.guide_nodes = has_guide ? (uint32_t)guide_nodes.size() : 0u;
+    sc.trace_mode = !large ? PT_TRACE_LOCKSTEP : (has_guide ? PT_TRACE_ORDERED : PT_TRACE_STREAM);
     if (ctx->trace_mode_override >= 0) sc.trace_mode = (uint32_t)ctx->trace_mode_override;
+    if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds
     sc.walk_flags = walk_flags;
     sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
     sc.has_procedural = 0;
@@ -623,7 +678,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     g.trace_lds_bytes = (size_t)sc.lds_nodes * sizeof(DevNode) + (size_t)sc.lds_prims * sizeof(DevPrim) + stack_bytes;
     // Waves per CU of the persistent grid: 32 (8 per SIMD) when every kernel of the pass fits 8 waves per SIMD (small
     // scene, solid textures); otherwise 24, a whole number of rounds for kernels that fit 6, 3 or 2 (no ragged last round).
-    uint32_t blocks_per_cu = (sc.trace_mode != PT_TRACE_STACK && !sc.has_procedural) ? 8u : 6u;
+    uint32_t blocks_per_cu = (sc.trace_mode != PT_TRACE_STACK && sc.trace_mode != PT_TRACE_ORDERED && !sc.has_procedural) ? 8u : 6u;
     if (ctx->blocks_per_cu_override > 0) blocks_per_cu = (uint32_t)ctx->blocks_per_cu_override;
     g.grid = (uint32_t)ctx->cu_count * blocks_per_cu;
     ctx->has_scene = true;

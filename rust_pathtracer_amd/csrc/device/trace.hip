@@ -133,8 +133,91 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
     }
 }
 
+// Larger scenes, ordered: nearest-first over the guide tree, then the proof that the reference's walk agrees
+// (pt_device.h OrderedWalk).  Same refill scheme as trace_stream_kernel; a lane's pending far children wait on a stack in
+// LDS laid out [level][thread].  The wave runs one kind of step at a time -- box tests (guide and verification),
+// primitive tests, or the literal walk; every step ends by issuing the lane's next fetch, so lanes that sit out a round
+// are waiting for memory anyway.
+// `io` supplies ray k of this wave's n rays and takes its result: the render kernel's region of the ray stream, or a
+// slice of the caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
+template <class RayIo>
+__device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
+    uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
+    uint32_t mine = 0;
+    OrderedWalk w;
+#ifdef PT_DEBUG_BOUNDS
+    w.w.lim = sc.stream_bytes;
+#endif
+    w.begin(sc, v3(0, 0, 0), v3(1, 1, 1), t_min, t_max);
+    w.mode = PT_OW_IDLE;
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (next < n && n_idle >= PT_REFILL_LANES) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t k = next + rank;
+            if (w.mode == PT_OW_IDLE && k < n) {
+                mine = k;
+                V3 o, d;
+                io.load(k, o, d);
+                w.begin(sc, o, d, t_min, t_max);
+            }
+            next = min(n, next + n_idle);
+        } else if (n_idle == 64u) {
+            break;
+        }
+        const uint32_t mode_before = w.mode;
+        // box tests (guide steps and the one verification step) together, primitive tests together
+        const uint32_t n_box = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE || w.mode == PT_OW_VERIFY));
+        const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
+        const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LITERAL));
+        if (n_box != 0u && n_leaf < PT_LEAF_LANES && n_literal < PT_LEAF_LANES) {
+#pragma unroll
+            for (int r = 0; r < PT_NODE_STEPS; ++r) {
+                if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack);
+                else if (w.mode == PT_OW_VERIFY) w.step_verify(sc);
+            }
+        } else if (n_leaf >= n_literal) {
+            if (w.mode == PT_OW_LEAF) w.step_leaf(sc, stack);
+        } else {
+            if (w.mode == PT_OW_LITERAL) w.step_literal(sc); // rare: one step per round keeps the kernel small
+        }
+        if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE) io.store(mine, w.w.o, w.w.d, w.result_t(), w.w.best_prim);
+    }
+}
+
+struct RegionRayIo { // the wave's region of the wavefront ray stream
+    RayStream rays;
+    double* hit_t;
+    int32_t* hit_prim;
+    size_t base;
+    __device__ __forceinline__ void load(uint32_t k, V3& o, V3& d) const {
+        const double2 a = rays.a[base + k], b = rays.b[base + k], c = rays.c[base + k];
+        o = v3(a.x, a.y, b.x);
+        d = v3(b.y, c.x, c.y);
+    }
+    __device__ __forceinline__ void store(uint32_t k, V3, V3, double t, int32_t prim) const {
+        hit_t[base + k] = t;
+        hit_prim[base + k] = prim;
+    }
+};
+
+__global__ __launch_bounds__(PT_BLOCK) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
+                                                                 uint32_t n_waves, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
+    __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
+    const uint32_t wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(counts[wave]);
+    RegionRayIo io{rays, hit_t, hit_prim, (size_t)wave * counts[n_waves]};
+    ordered_wave_loop(sc, s_stack + threadIdx.x, n, 0.001, __builtin_huge_val(), io); // ray.rs:25
+}
+
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io) {
     const RayStream& in = wf.rays[io.in];
+    if (sc.trace_mode == PT_TRACE_ORDERED) {
+        hipLaunchKernelGGL(trace_ordered_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes}, in,
+                           io.counts_in, wf.n_waves, wf.hit_t, wf.hit_prim);
+        return;
+    }
     if (sc.trace_mode == PT_TRACE_STREAM) {
         hipLaunchKernelGGL(trace_stream_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc.walk, sc.walk_bytes, in, io.counts_in, wf.n_waves,
                            wf.hit_t, wf.hit_prim);
@@ -192,6 +275,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_kernel(DevScene sc, cons
 
 __device__ __forceinline__ void write_hit_record(const DevScene& sc, V3 o, V3 d, double t, int32_t prim, PtHitOut* out) {
     PtHitOut h;
+    if (prim >= (int32_t)sc.n_prims) prim = -1; // cannot happen; keeps the table reads below in range regardless
     h.prim = prim;
     if (prim >= 0) {
         const DevPrim* pr = sc.prims + prim;
@@ -246,11 +330,42 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_stream_kernel(DevScene s
     }
 }
 
+struct BatchRayIo { // a slice of the caller's arrays (AoS, as the C ABI takes them), full hit record out
+    const DevScene* sc;
+    const double* origins;
+    const double* dirs;
+    PtHitOut* out;
+    size_t first;
+    __device__ __forceinline__ void load(uint32_t k, V3& o, V3& d) const {
+        const size_t i = first + k;
+        o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+        d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    }
+    __device__ __forceinline__ void store(uint32_t k, V3 o, V3 d, double t, int32_t prim) const { write_hit_record(*sc, o, d, t, prim, out + first + k); }
+};
+
+__global__ __launch_bounds__(PT_BLOCK) void trace_batch_ordered_kernel(DevScene sc, const double* __restrict__ origins,
+                                                                       const double* __restrict__ dirs, uint32_t n, double t_min,
+                                                                       double t_max, PtHitOut* __restrict__ out) {
+    __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
+    const OrderedScene os{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes};
+    const uint32_t waves = gridDim.x * (blockDim.x / PT_WAVE), wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
+    const uint32_t per_wave = (n + waves - 1u) / waves; // rays [wave * per_wave, ...) belong to this wave
+    const uint64_t first = (uint64_t)wave * per_wave;
+    const uint32_t mine = first >= n ? 0u : (uint32_t)min((uint64_t)per_wave, (uint64_t)n - first);
+    BatchRayIo io{&sc, origins, dirs, out, (size_t)first};
+    ordered_wave_loop(os, s_stack + threadIdx.x, mine, t_min, t_max, io);
+}
+
 void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const double* origins, const double* dirs,
                         uint32_t n, double t_min, double t_max, PtHitOut* out) {
     uint32_t blocks = (n + PT_BLOCK - 1) / PT_BLOCK;
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) blocks = 1;
+    if (sc.trace_mode == PT_TRACE_ORDERED) {
+        hipLaunchKernelGGL(trace_batch_ordered_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, sc, origins, dirs, n, t_min, t_max, out);
+        return;
+    }
     if (sc.trace_mode == PT_TRACE_STREAM) {
         hipLaunchKernelGGL(trace_batch_stream_kernel, dim3(blocks), dim3(PT_BLOCK), 0, s, sc, origins, dirs, n, t_min, t_max, out);
         return;

@@ -6,11 +6,13 @@ w, h, spp, depth = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 8, 50
 s = pt.Scene("ModelTest").set_seeds(1, 1, 1).set_model_synthetic(1000, 501, 150.0, (0.0, 150.0, 0.0), 100.0)
 s.set_image(w, h, spp, depth, (1, 1, 1)).build()
 cam = s.camera(0.0)
-for mode in (1, 2):
+for mode in (2, 3):
     ctx = pt.Context(0)
     ctx.set_option("trace_mode", mode)
     ctx.set_option("lanes", 1)
+    t0 = time.perf_counter()
     ctx.upload(s)
+    print('upload s', round(time.perf_counter() - t0, 2))
     for rep in range(2):
         ctx.accum_reset(w, h)
         t0 = time.perf_counter()

@@ -134,11 +134,12 @@ def test_trace_edge_cases(gpu_ctx, oracle):
         assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 def test_every_trace_kernel_gives_the_same_hits(gpu_ctx, oracle, mode):
-    """The three walkers of the record stream / node table -- wave-uniform lockstep (0), per-lane with an LDS stack (1),
-    per-lane stackless over the stream (2) -- forced in turn on a world that would normally take the per-lane stream
-    walk and on one that would take the lockstep walk."""
+    """The four walkers of the record stream / node table -- wave-uniform lockstep (0), per-lane with an LDS stack (1),
+    per-lane stackless over the stream (2), nearest-first over the guide tree with the proof that the reference's walk
+    agrees (3) -- forced in turn on a world that would normally take the ordered walk and on one that would take the
+    lockstep walk."""
     try:
         gpu_ctx.set_option("trace_mode", mode)
         for seed, n_objects, mesh in [(21, 60, True), (22, 12, False)]:
@@ -154,6 +155,78 @@ def test_every_trace_kernel_gives_the_same_hits(gpu_ctx, oracle, mode):
             stats, got, want, rays = render_pair(gpu_ctx, o, cam, w, h, bg, 0, 3, 12, 5)
             assert stats.rays == rays
             assert_images_close(got, want, 3)
+    finally:
+        gpu_ctx.set_option("trace_mode", -1)
+
+
+def _tie_world(bvh_seed):
+    """Primitives that meet exactly: a grid of unit boxes sharing faces, a floor in the plane of their bottoms, a sheet in
+    the plane of their tops, the same sphere three times, touching spheres, a fan of triangles around one apex (both
+    windings), one triangle twice.  All coordinates dyadic, so rays aimed at the seams hit several primitives at
+    bit-identical t: which one the reference reports depends on the order of ITS tree (bvh.rs:107-121)."""
+    texs = [su._tex(0, color=(0.7, 0.7, 0.7))]
+    mats = [su._mat(0, 0)]
+    objs = []
+    for i in range(4):
+        for j in range(4):
+            objs.append(su._obj(4, 0, [i, 0, j, i + 1, 1, j + 1]))
+    objs.append(su._obj(2, 0, [-2, 0.0, -2, 6, 0.0, 6, 1.0]))
+    objs.append(su._obj(2, 0, [-1, 1.0, -1, 5, 1.0, 5, 1.0]))
+    for _ in range(3):
+        objs.append(su._obj(0, 0, [2, 3, 2, 1.0]))
+    objs.append(su._obj(0, 0, [4, 3, 2, 1.0]))
+    apex = (2.0, 5.0, 2.0)
+    ring = [(2.0 + dx, 4.5, 2.0 + dz) for dx, dz in [(2, 0), (1.5, 1.5), (0, 2), (-1.5, 1.5), (-2, 0), (-1.5, -1.5), (0, -2), (1.5, -1.5)]]
+    for k in range(8):
+        objs.append(su._obj(6, 0, [*apex, *ring[(k + 1) % 8], *ring[k]]))
+        objs.append(su._obj(6, 0, [*apex, *ring[k], *ring[(k + 1) % 8]]))
+    objs.append(su._obj(6, 0, [*apex, *ring[1], *ring[0]]))
+    ps = su.pt.world_create([o[0] for o in objs], [m[0] for m in mats], [t[0] for t in texs], bvh_seed=bvh_seed)
+    os_ = su.orc.OracleScene.custom([o[1] for o in objs], [m[1] for m in mats], [t[1] for t in texs], [], [], bvh_seed=bvh_seed)
+    return ps, os_, apex, ring
+
+
+@pytest.mark.parametrize("bvh_seed", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("mode", [2, 3])
+def test_trace_ties_follow_the_reference_tree(gpu_ctx, oracle, mode, bvh_seed):
+    """Equal-t hits: the per-lane literal walk (2) reproduces the reference's order by construction; the ordered walk (3)
+    must notice every tie and near tie and hand those rays to the literal walk (pt_device.h OrderedWalk)."""
+    try:
+        gpu_ctx.set_option("trace_mode", mode)
+        s, o, apex, ring = _tie_world(bvh_seed)
+        gpu_ctx.upload(s)
+        rng = np.random.default_rng(100 + bvh_seed)
+        n = 20000
+        # targets on the seams: grid corners and edge points of the box tops / bottoms, the fan's apex, ring and edges
+        grid = np.stack([rng.integers(0, 5, n), rng.integers(0, 2, n), rng.integers(0, 5, n)], axis=1).astype(float)
+        edge = grid.copy()
+        edge[:, 0] += rng.integers(0, 2, n) * 0.5
+        edge[:, 2] += rng.integers(0, 2, n) * 0.25
+        pts = np.array([apex] + ring + [tuple((np.array(apex) + np.array(r)) / 2) for r in ring] +
+                       [tuple((np.array(ring[k]) + np.array(ring[(k + 1) % 8])) / 2) for k in range(8)])
+        fan = pts[rng.integers(0, len(pts), n)]
+        sph = np.array([[3.0, 3.0, 2.0], [2.0, 3.0, 2.0], [2.0, 4.0, 2.0]])[rng.integers(0, 3, n)]  # the touching point, the shared centre
+        targets = np.concatenate([grid, edge, fan, sph])
+        origins = np.round(rng.uniform(-3, 8, targets.shape) * 4) / 4  # dyadic, so that o + t d lands exactly on the seam
+        origins[:, 1] = np.abs(origins[:, 1]) + 1.25
+        origins[::5, 1] = -1.0  # some from below the floor
+        dirs = targets - origins
+        dirs[::3] *= 0.5
+        # rays starting exactly in the planes y = 0 and y = 1, and axis-parallel ones along the seams
+        flat_o = np.stack([rng.uniform(-1, 5, n), rng.integers(0, 2, n).astype(float), rng.uniform(-1, 5, n)], axis=1)
+        flat_d = rng.normal(size=(n, 3))
+        down_o = np.stack([rng.integers(0, 5, n).astype(float), np.full(n, 7.0), rng.uniform(0, 4, n)], axis=1)
+        down_d = np.tile([0.0, -1.0, 0.0], (n, 1))
+        ro = np.concatenate([origins, flat_o, down_o])
+        rd = np.concatenate([dirs, flat_d, down_d])
+        with np.errstate(all="ignore"):
+            prim, t, normal, front = o.trace(ro, rd)
+        assert (prim >= 0).mean() > 0.5
+        assert_hits_equal(gpu_ctx.trace_batch(ro, rd), prim, t, normal, front)
+        for t_min, t_max in [(0.0, 1.0), (0.5, 1.0), (1.0, 4.0)]:  # with d = target - origin the seam is at t = 1 exactly
+            with np.errstate(all="ignore"):
+                prim, t, normal, front = o.trace(ro[: 4 * n], rd[: 4 * n], t_min, t_max)
+            assert_hits_equal(gpu_ctx.trace_batch(ro[: 4 * n], rd[: 4 * n], t_min, t_max), prim, t, normal, front)
     finally:
         gpu_ctx.set_option("trace_mode", -1)
 
