@@ -124,14 +124,14 @@ typedef struct PtStats {
     uint32_t passes;          /* wavefront passes the call was split into */
     uint32_t launches_trace;  /* trace kernel launches */
     uint32_t launches_shade;
-    uint32_t launches_path;   /* fused path-kernel launches (one per sub-pass; then there are no trace / shade launches) */
+    uint32_t launches_path;   /* fused path-kernel / tail-kernel launches (at most one per sub-pass) */
     double ms_total;          /* first launch to last completion */
     double ms_raygen;
     double ms_trace;
     double ms_shade;
     double ms_fold;
     double ms_repack;
-    double ms_path;           /* the fused path kernel (trace + shade of every bounce in one launch) */
+    double ms_path;           /* the fused path kernel / the tail kernel (trace + shade of several bounces in one launch) */
     uint64_t rays_per_bounce[64]; /* live rays entering bounce b (b >= 64 folded into the last slot) */
 } PtStats;
 
@@ -157,9 +157,13 @@ const char* pt_last_error(const PtContext* ctx);
  * "fused" (1 = scenes that take the lockstep walk and have only solid textures run the whole bounce loop of a sub-pass in one
  *   launch, each wave on its own region; 0 = one trace and one shade launch per bounce; default 0 -- the fused kernel needs 87
  *   VGPRs, runs 5 waves per SIMD instead of 8 and measures 10-15 % slower on the Cornell box; results are identical),
- * "trace_mode" (which kernel answers the hit queries, applied at the next pt_scene_upload: -1 = by scene size, 0 = wave-uniform
- *   lockstep walk, 1 = per-lane walk with an LDS stack, 2 = per-lane stackless walk of the record stream; all three give
- *   identical results),
+ * "trace_mode" (which kernel answers the hit queries, applied at the next pt_scene_upload: -1 = by scene size (0 up to 192
+ *   nodes + primitives, 3 beyond), 0 = wave-uniform lockstep walk, 1 = per-lane walk with an LDS stack, 2 = per-lane stackless
+ *   walk of the record stream, 3 = ordered walk: nearest-first over a surface-area guide tree built at upload, then a
+ *   proof per ray that the reference's walk returns the same primitive, else the walk of mode 2 for that ray; falls back
+ *   to 2 when the scene's boxes are not finite and nested; all four give identical results),
+ * "tail_from" (ordered walk: bounces from this one on run in ONE launch per sub-pass, each wave looping over its own
+ *   rays; -1 = automatic: 4 for scenes of 65536 primitives or more, never otherwise; results are identical),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 

@@ -56,6 +56,10 @@ void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
                   const BounceIO& io, uint32_t bounce);
 // The whole bounce loop in one launch (path.hip); the count rows 1.. of wf.counts must have been zeroed.
 void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf);
+// Bounces first_bounce.. of the pass in one launch, each wave on its own region (ordered walk only); io.in / io.counts_in: where
+// first_bounce's rays and counts are.
+void launch_tail(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf, const BounceIO& io,
+                 uint32_t first_bounce);
 struct ShadeEnv;
 ShadeEnv make_shade_env(const PassParams& p, const Wavefront& wf, uint32_t bounce);
 // Re-deals the rays of buffer io.in evenly over the waves into buffer io.out (counts_in -> counts_out).

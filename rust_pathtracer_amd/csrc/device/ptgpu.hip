@@ -9,6 +9,12 @@
 #include "pt_launch.h"
 
 #define PT_MAX_LANES 8
+#ifndef PT_TAIL_FROM_DEFAULT
+#define PT_TAIL_FROM_DEFAULT 4u
+#endif
+#ifndef PT_TAIL_MIN_PRIMS
+#define PT_TAIL_MIN_PRIMS 65536u
+#endif
 
 namespace {
 thread_local std::string g_last_error;
@@ -58,6 +64,7 @@ struct PtContext {
     int profile = 1;
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
+    int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
     int fused = 0;                // one path kernel per pass where it applies (measured: not faster, see path.hip)
     int repack_every = 0, repack_first = 8;  // measured on Cornell 1080p: the copy costs more than the fuller waves save
     std::vector<hipEvent_t> events;
@@ -326,6 +333,9 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
         ctx->repack_first = (int)value;
     } else if (k == "fused") {  // 1: the whole bounce loop in one launch where the lockstep walk applies; 0: a trace and a shade launch per bounce
         ctx->fused = value ? 1 : 0;
+    } else if (k == "tail_from") {  // ordered walk: bounces from this one on run in one per-wave launch (path.hip); -1 automatic
+        if (value < -1 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "tail_from out of range [-1, 4096]");
+        ctx->tail_from = (int)value;
     } else if (k == "trace_mode") {  // -1 automatic, 0 lockstep walk, 1 per-lane stack (LDS), 2 per-lane record stream, 3 ordered; next upload
         if (value < -1 || value > 3) return ctx->fail(PT_ERR_BAD_ARG, "trace_mode out of range [-1, 3]");
         ctx->trace_mode_override = (int)value;
@@ -799,9 +809,18 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
 
     // Event bookkeeping.  Every launch is bracketed by two events on its own stream; the stop event doubles as the
     // hand-off the other lane waits on.
-    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5, K_PATH = 6 };
+    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5, K_PATH = 6, K_TAIL = 7 };
     // one launch for the whole bounce loop (path.hip) where the wave-uniform walk applies and textures are solid
     const bool fused = ctx->fused && ctx->sc.trace_mode == PT_TRACE_LOCKSTEP && !ctx->sc.has_procedural && ctx->repack_every == 0;
+    // ordered walk: the first few bounces as a trace and a shade launch each, the thinned-out rest in one per-wave launch.
+    // Automatic: only for scenes with deep trees (a million triangles: a launch of few rays lasts as long as its slowest
+    // ray's hundreds of dependent fetches, 29 -> 21 ms per 8-spp frame); SphereField's late bounces are cheap launches and
+    // run better on the separate kernels' higher occupancy.
+    uint32_t tail_from = max_bounces;
+    if (ctx->sc.trace_mode == PT_TRACE_ORDERED && ctx->repack_every == 0) {
+        if (ctx->tail_from >= 0) tail_from = (uint32_t)ctx->tail_from;
+        else if (ctx->sc.n_prims >= PT_TAIL_MIN_PRIMS) tail_from = PT_TAIL_FROM_DEFAULT;
+    }
     struct Timed { int kind; size_t start, stop; };
     std::vector<Timed> timed;
     size_t ev_used = 0;
@@ -831,6 +850,10 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         const uint32_t* counts_in = wf.counts;
         if (fused) pl.steps.push_back({K_PATH, 0, BounceIO{0, 1, nullptr, nullptr}});
         for (uint32_t b = 0; b < max_bounces && !fused; ++b) {
+            if (b == tail_from) {
+                pl.steps.push_back({K_TAIL, b, BounceIO{buf, buf ^ 1, counts_in, nullptr}});
+                break;
+            }
             BounceIO io{buf, buf ^ 1, counts_in, wf.counts + count_row(wf, b + 1)};
             pl.steps.push_back({K_TRACE, b, io});
             pl.steps.push_back({K_SHADE, b, io});
@@ -898,6 +921,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                         launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf);
                         break;
                     case K_PATH: launch_path(ln.stream, geom, ctx->sc, plan[l].p, ln.wf); ++launches_path; break;
+                    case K_TAIL: launch_tail(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_path; break;
                     case K_TRACE: launch_trace(ln.stream, geom, ctx->sc, ln.wf, st.io); ++launches_trace; break;
                     case K_SHADE: launch_shade(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_shade; break;
                     case K_REPACK: launch_repack(ln.stream, geom, ln.wf, st.io); break;
@@ -955,6 +979,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_FOLD: stats->ms_fold += ms; break;
                     case K_REPACK: stats->ms_repack += ms; break;
                     case K_PATH: stats->ms_path += ms; break;
+                    case K_TAIL: stats->ms_path += ms; break;
                     default: break;
                 }
             }

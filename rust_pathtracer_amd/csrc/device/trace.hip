@@ -4,7 +4,7 @@
 // the scene prefix (the top BVH levels, or the whole scene when it is small) in LDS once.  A lane's pending right children sit on a stack in
 // LDS laid out [level][thread], so a wave's push/pop touches 64 consecutive banks.
 // Reads 48 B/ray (three coalesced 16-B streams), writes 12 B/ray (t, primitive).
-#include "pt_launch.h"
+#include "pt_ordered.h"
 
 __device__ __forceinline__ void stage_scene(const DevScene& sc, unsigned char* smem) {
     // nodes are 64 B, primitives 80 B: copy as 16-B pieces
@@ -77,15 +77,6 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const unsigned cha
 // Rays differ widely in the number of records they visit (SphereField: 40 on average, 120 for the slowest of 64), so a
 // lane does not wait for its wave: whenever PT_REFILL_LANES lanes are out of work, each takes the next unassigned ray of the
 // wave's region (rank among the idle lanes by ballot + mbcnt; the region is private to the wave, so no atomics).
-#ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 16
-#endif
-#ifndef PT_NODE_STEPS
-#define PT_NODE_STEPS 4
-#endif
-#ifndef PT_LEAF_LANES
-#define PT_LEAF_LANES 24
-#endif
 __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned char* __restrict__ stream, uint32_t stream_bytes, RayStream rays,
                                                                 const uint32_t* __restrict__ counts, uint32_t n_waves,
                                                                 double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
@@ -132,75 +123,6 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
         }
     }
 }
-
-// Larger scenes, ordered: nearest-first over the guide tree, then the proof that the reference's walk agrees
-// (pt_device.h OrderedWalk).  Same refill scheme as trace_stream_kernel; a lane's pending far children wait on a stack in
-// LDS laid out [level][thread].  The wave runs one kind of step at a time -- box tests (guide and verification),
-// primitive tests, or the literal walk; every step ends by issuing the lane's next fetch, so lanes that sit out a round
-// are waiting for memory anyway.
-// `io` supplies ray k of this wave's n rays and takes its result: the render kernel's region of the ray stream, or a
-// slice of the caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
-template <class RayIo>
-__device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
-    uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
-    uint32_t mine = 0;
-    OrderedWalk w;
-#ifdef PT_DEBUG_BOUNDS
-    w.w.lim = sc.stream_bytes;
-#endif
-    w.begin(sc, v3(0, 0, 0), v3(1, 1, 1), t_min, t_max);
-    w.mode = PT_OW_IDLE;
-    for (;;) {
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE);
-        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (next < n && n_idle >= PT_REFILL_LANES) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const uint32_t k = next + rank;
-            if (w.mode == PT_OW_IDLE && k < n) {
-                mine = k;
-                V3 o, d;
-                io.load(k, o, d);
-                w.begin(sc, o, d, t_min, t_max);
-            }
-            next = min(n, next + n_idle);
-        } else if (n_idle == 64u) {
-            break;
-        }
-        const uint32_t mode_before = w.mode;
-        // box tests (guide steps and the one verification step) together, primitive tests together
-        const uint32_t n_box = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE || w.mode == PT_OW_VERIFY));
-        const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
-        const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LITERAL));
-        if (n_box != 0u && n_leaf < PT_LEAF_LANES && n_literal < PT_LEAF_LANES) {
-#pragma unroll
-            for (int r = 0; r < PT_NODE_STEPS; ++r) {
-                if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack);
-                else if (w.mode == PT_OW_VERIFY) w.step_verify(sc);
-            }
-        } else if (n_leaf >= n_literal) {
-            if (w.mode == PT_OW_LEAF) w.step_leaf(sc, stack);
-        } else {
-            if (w.mode == PT_OW_LITERAL) w.step_literal(sc); // rare: one step per round keeps the kernel small
-        }
-        if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE) io.store(mine, w.w.o, w.w.d, w.result_t(), w.w.best_prim);
-    }
-}
-
-struct RegionRayIo { // the wave's region of the wavefront ray stream
-    RayStream rays;
-    double* hit_t;
-    int32_t* hit_prim;
-    size_t base;
-    __device__ __forceinline__ void load(uint32_t k, V3& o, V3& d) const {
-        const double2 a = rays.a[base + k], b = rays.b[base + k], c = rays.c[base + k];
-        o = v3(a.x, a.y, b.x);
-        d = v3(b.y, c.x, c.y);
-    }
-    __device__ __forceinline__ void store(uint32_t k, V3, V3, double t, int32_t prim) const {
-        hit_t[base + k] = t;
-        hit_prim[base + k] = prim;
-    }
-};
 
 __global__ __launch_bounds__(PT_BLOCK) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
                                                                  uint32_t n_waves, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {

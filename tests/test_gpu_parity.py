@@ -432,6 +432,58 @@ def test_scheduling_options_do_not_change_results(gpu_ctx, pt, oracle):
         ctx.close()
 
 
+def _solid_sphere_world(n, seed):
+    """n spheres with solid textures only (the shade kernels without procedural textures, tables not in LDS)."""
+    rng = np.random.default_rng(seed)
+    texs = [su._tex(0, color=rng.uniform(0.2, 0.9, 3)) for _ in range(6)] + [su._tex(0, color=(6.0, 5.0, 4.0))]
+    mats = [su._mat(0, 0), su._mat(0, 1), su._mat(1, 2, 0.0), su._mat(1, 3, 0.4), su._mat(2, 0, 1.5), su._mat(0, 4), su._mat(3, 6)]
+    objs = [su._obj(0, 5, [0.0, -1000.0, 0.0, 1000.0])]
+    for _ in range(n):
+        c = rng.uniform(-9, 9, 3)
+        c[1] = rng.uniform(0.2, 3.0)
+        objs.append(su._obj(0, int(rng.integers(0, len(mats))), [*c, rng.uniform(0.15, 0.6)]))
+    ps = su.pt.world_create([o[0] for o in objs], [m[0] for m in mats], [t[0] for t in texs], bvh_seed=seed)
+    os_ = su.orc.OracleScene.custom([o[1] for o in objs], [m[1] for m in mats], [t[1] for t in texs], [], [], bvh_seed=seed)
+    return ps, os_
+
+
+@pytest.mark.parametrize("world", ["SphereField", "solid spheres", "CornellBox"])
+def test_ordered_walk_scheduling_does_not_change_results(pt, oracle, world):
+    """The ordered walk's pass: the first bounces as trace + shade launches, the rest in one per-wave launch (tail_from), on
+    one to three lanes, in one pass or several -- against the literal per-lane walk with separate launches, and the oracle.
+    The three worlds take the three table layouts of the tail kernel (procedural textures; solid, tables in global memory;
+    solid, tables in LDS -- the Cornell box forced onto the ordered walk)."""
+    w, h, spp, depth, seed = 64, 36, 6, 30, 3
+    bg = (0.7, 0.8, 1.0)
+    ctx = pt.Context(0)
+    try:
+        if world == "solid spheres":
+            s, o = _solid_sphere_world(260, 5)
+            cam = api.camera_new((13.0, 3.0, 4.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 35.0, w / h, 0.05, 10.0)
+        else:
+            s, o = su.named_pair(world, 1, 1, 1, image=(w, h, spp, depth, bg))
+            cam = s.camera(0.3)
+        results = []
+        for opts in [dict(trace_mode=2), dict(trace_mode=3, tail_from=4096), dict(trace_mode=3, tail_from=0), dict(trace_mode=3, tail_from=1, lanes=1),
+                     dict(trace_mode=3, tail_from=3, lanes=3), dict(trace_mode=3, tail_from=2, paths_per_pass=w * h * 2), dict(trace_mode=3, tail_from=-1),
+                     dict(trace_mode=3, tail_from=depth - 1), dict(trace_mode=3, tail_from=5, blocks_per_cu=2)]:
+            defaults = dict(lanes=2, paths_per_pass=1 << 29, blocks_per_cu=0, tail_from=-1)
+            for k, v in {**defaults, **opts}.items():
+                ctx.set_option(k, v)
+            ctx.upload(s)
+            ctx.accum_reset(w, h)
+            st = ctx.render_accumulate(cam, w, h, bg, 0, spp, depth, seed)
+            results.append((st.rays, list(st.rays_per_bounce), ctx.accum_download(), st.launches_path))
+        assert results[0][3] == 0 and results[1][3] == 0 and results[2][3] > 0
+        want, rays = o.render_accumulate(cam.as_array(), w, h, bg, 0, spp, depth, seed)
+        for r, rpb, img, _ in results:
+            assert r == rays and rpb == results[0][1]
+            assert np.allclose(img, results[0][2], rtol=1e-5, atol=1e-5)
+            assert_images_close(img.astype(np.float64), want, spp)
+    finally:
+        ctx.close()
+
+
 def test_depth_zero_and_background(gpu_ctx, pt):
     s = pt.Scene("TwoSpheres").set_image(16, 8, 2, 3, (1, 1, 1)).build()
     gpu_ctx.upload(s)
