@@ -3,14 +3,16 @@
 #pragma once
 #include "pt_launch.h"
 
-#ifndef PT_REFILL_LANES
-#define PT_REFILL_LANES 16
+// Measured on SphereField (1080p, 32 spp): handing out rays when 40 lanes are idle, primitive tests when 16 lanes wait
+// for one, four box tests per round: 26.9 ms of trace per frame (16 / 24 / 4, the stream walk's values: 29.7 ms).
+#ifndef PT_ORD_REFILL_LANES
+#define PT_ORD_REFILL_LANES 40
 #endif
-#ifndef PT_NODE_STEPS
-#define PT_NODE_STEPS 4
+#ifndef PT_ORD_NODE_STEPS
+#define PT_ORD_NODE_STEPS 4
 #endif
-#ifndef PT_LEAF_LANES
-#define PT_LEAF_LANES 24
+#ifndef PT_ORD_LEAF_LANES
+#define PT_ORD_LEAF_LANES 16
 #endif
 // Larger scenes, ordered: nearest-first over the guide tree, then the proof that the reference's walk agrees
 // (pt_device.h OrderedWalk).  Same refill scheme as trace_stream_kernel; a lane's pending far children wait on a stack in
@@ -32,7 +34,7 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
     for (;;) {
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (next < n && n_idle >= PT_REFILL_LANES) {
+        if (next < n && n_idle >= PT_ORD_REFILL_LANES) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t k = next + rank;
             if (w.mode == PT_OW_IDLE && k < n) {
@@ -50,9 +52,9 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
         const uint32_t n_box = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE || w.mode == PT_OW_VERIFY));
         const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
         const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LITERAL));
-        if (n_box != 0u && n_leaf < PT_LEAF_LANES && n_literal < PT_LEAF_LANES) {
+        if (n_box != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) {
 #pragma unroll
-            for (int r = 0; r < PT_NODE_STEPS; ++r) {
+            for (int r = 0; r < PT_ORD_NODE_STEPS; ++r) {
                 if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack);
                 else if (w.mode == PT_OW_VERIFY) w.step_verify(sc);
             }

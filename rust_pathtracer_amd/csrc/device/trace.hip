@@ -77,6 +77,15 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_walk_kernel(const unsigned cha
 // Rays differ widely in the number of records they visit (SphereField: 40 on average, 120 for the slowest of 64), so a
 // lane does not wait for its wave: whenever PT_REFILL_LANES lanes are out of work, each takes the next unassigned ray of the
 // wave's region (rank among the idle lanes by ballot + mbcnt; the region is private to the wave, so no atomics).
+#ifndef PT_REFILL_LANES
+#define PT_REFILL_LANES 16
+#endif
+#ifndef PT_NODE_STEPS
+#define PT_NODE_STEPS 4
+#endif
+#ifndef PT_LEAF_LANES
+#define PT_LEAF_LANES 24
+#endif
 __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned char* __restrict__ stream, uint32_t stream_bytes, RayStream rays,
                                                                 const uint32_t* __restrict__ counts, uint32_t n_waves,
                                                                 double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
