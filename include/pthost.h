@@ -109,6 +109,12 @@ int pth_write_png(const char* path, uint32_t width, uint32_t height, const uint8
 int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_dir, uint32_t first_frame, uint32_t frame_stride,
                       uint32_t max_frames, uint32_t* frames_total, uint32_t* frames_written, double* seconds_render, double* seconds_write,
                       uint64_t* rays);
+/* BASELINE.json configs[4] asks for the world to be rebuilt and uploaded for every frame (the reference builds it once,
+ * main.rs:23).  on = 1: pth_render_frames runs scene.get_world() (BvhNode::new, same seeds, hence the same tree) and the
+ * upload before each frame; the time that takes is kept apart from seconds_render and read back with
+ * pth_scene_rebuild_seconds after the call.  Fails for worlds made by pth_world_create (no scene to rebuild from). */
+int pth_scene_set_rebuild_per_frame(PthScene* s, int on);
+int pth_scene_rebuild_seconds(PthScene* s, double* seconds_build, double* seconds_upload);
 /* OBJ reader probe: number of models / triangles / materials the reader finds in a file (-1 on error). */
 int pth_obj_probe(const char* path, uint32_t* n_models, uint64_t* n_triangles, uint32_t* n_materials);
 

@@ -216,6 +216,8 @@ _PTHOST_PROTOS = {
     "pth_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _vp]),
     "pth_render_frames": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "pth_scene_set_rebuild_per_frame": (C.c_int, [_vp, C.c_int]),
+    "pth_scene_rebuild_seconds": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pth_obj_probe": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
 }
 for _name, (_res, _args) in _PTGPU_PROTOS.items():
@@ -342,15 +344,19 @@ class Scene:
         self._ok(libpthost.pth_render(self._h, device, t, seed, out.ctypes.data, C.byref(stats)))
         return out, stats
 
-    def render_frames(self, out_dir: str, device: int = 0, seed: int = 0, first_frame: int = 0, frame_stride: int = 1, max_frames: int = 0):
+    def render_frames(self, out_dir: str, device: int = 0, seed: int = 0, first_frame: int = 0, frame_stride: int = 1, max_frames: int = 0,
+                      rebuild_per_frame: bool = False):
         """The frame loop of main.rs:24-72: renders the scene's frames (one for a static image) and writes
-        out_dir/image_%04d.png, encoding each PNG while the next frame renders."""
+        out_dir/image_%04d.png, encoding each PNG while the next frame renders.  rebuild_per_frame: BvhNode::new and the
+        upload again before every frame (BASELINE.json configs[4]); their time is reported apart."""
         total, written, rays = C.c_uint32(), C.c_uint32(), C.c_uint64()
-        t_render, t_write = C.c_double(), C.c_double()
+        t_render, t_write, t_build, t_upload = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        self._ok(libpthost.pth_scene_set_rebuild_per_frame(self._h, 1 if rebuild_per_frame else 0))
         self._ok(libpthost.pth_render_frames(self._h, device, seed, os.fsencode(out_dir), first_frame, frame_stride, max_frames,
                                              C.byref(total), C.byref(written), C.byref(t_render), C.byref(t_write), C.byref(rays)))
+        self._ok(libpthost.pth_scene_rebuild_seconds(self._h, C.byref(t_build), C.byref(t_upload)))
         return {"frames_total": total.value, "frames_written": written.value, "seconds_render": t_render.value,
-                "seconds_write": t_write.value, "rays": rays.value}
+                "seconds_write": t_write.value, "rays": rays.value, "seconds_build": t_build.value, "seconds_upload": t_upload.value}
 
     # flattened tables as numpy views (copies), for tests
     def nodes_array(self) -> np.ndarray:

@@ -31,6 +31,8 @@ struct PthScene {
     std::map<int, std::unique_ptr<GpuRenderer>> renderers; // per device
     std::map<int, bool> uploaded;
     std::shared_ptr<ObjFile> mesh; // ModelTest: the arrays the world was built from
+    bool rebuild_per_frame = false;
+    double seconds_build = 0.0, seconds_upload = 0.0; // of the last pth_render_frames call
 };
 
 template <class F>
@@ -326,6 +328,8 @@ int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_di
         const ImageSettings& im = o.image_settings;
         const uint64_t amount_of_frames = o.animation ? (uint64_t)(o.fps * o.duration) : 1;  // main.rs:25-32
         if (frames_total) *frames_total = (uint32_t)amount_of_frames;
+        s->seconds_build = s->seconds_upload = 0.0;
+        if (s->rebuild_per_frame && !s->scene) throw std::runtime_error("pth_render_frames: a world made by pth_world_create cannot be rebuilt");
         std::thread writer;
         std::string write_error;
         double t_render = 0.0, t_write = 0.0;
@@ -336,6 +340,14 @@ int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_di
              frame_index += frame_stride) {
             const double t = (double)frame_index / (double)amount_of_frames;  // main.rs:52
             PtStats st;
+            if (s->rebuild_per_frame) { // BvhNode::new and the upload again for this frame: same seeds, so the same world and image
+                const double b0 = now();
+                s->world = s->scene->get_world();
+                const double b1 = now();
+                r->upload(*s->world); // flattening, record stream, guide tree, copies
+                s->seconds_build += b1 - b0;
+                s->seconds_upload += now() - b1;
+            }
             const double t0 = now();
             std::vector<uint8_t> pixels = r->render(s->scene->get_camera_at(t), im.width, im.height, im.background,
                                                     im.samples_per_pixel, im.max_bounces, seed, &st);
@@ -361,6 +373,21 @@ int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_di
         if (seconds_render) *seconds_render = t_render;
         if (seconds_write) *seconds_write = t_write;
         if (rays) *rays = ray_sum;
+    });
+}
+
+int pth_scene_set_rebuild_per_frame(PthScene* s, int on) {
+    return guarded([&] {
+        if (!s) throw std::runtime_error("pth_scene_set_rebuild_per_frame: null scene");
+        s->rebuild_per_frame = on != 0;
+    });
+}
+
+int pth_scene_rebuild_seconds(PthScene* s, double* seconds_build, double* seconds_upload) {
+    return guarded([&] {
+        if (!s) throw std::runtime_error("pth_scene_rebuild_seconds: null scene");
+        if (seconds_build) *seconds_build = s->seconds_build;
+        if (seconds_upload) *seconds_upload = s->seconds_upload;
     });
 }
 

@@ -3,7 +3,7 @@
 // scene name and the ImageSettings overrides are arguments here.  Thin: everything happens in libpthost.
 //
 //   ptrender SCENE [--width W --height H --spp N --depth D] [--out DIR] [--device I] [--seed S]
-//                  [--frames N] [--first-frame K --frame-stride M] [--model PATH | --synthetic-mesh NLON NLAT]
+//                  [--frames N] [--first-frame K --frame-stride M] [--rebuild-per-frame] [--model PATH | --synthetic-mesh NLON NLAT]
 #include <sys/stat.h>
 
 #include <cstdio>
@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr,
                      "usage: ptrender SCENE [--width W --height H --spp N --depth D] [--out DIR] [--device I] [--seed S]\n"
-                     "                [--frames N] [--first-frame K --frame-stride M] [--model PATH | --synthetic-mesh NLON NLAT]\n"
+                     "                [--frames N] [--first-frame K --frame-stride M] [--rebuild-per-frame] [--model PATH | --synthetic-mesh NLON NLAT]\n"
                      "scenes: SphereField TwoSpheres LightTest CornellBox TriangleTest ModelTest\n");
         return 2;
     }
@@ -30,6 +30,7 @@ int main(int argc, char** argv) {
     std::string out = "./output", model;
     long width = 0, height = 0, spp = 0, depth = 0, device = 0, frames = 0, first = 0, stride = 1, nlon = 0, nlat = 0;
     unsigned long long seed = 1;
+    int rebuild = 0;
     for (int i = 2; i < argc; ++i) {
         auto need = [&](int n) {
             if (i + n >= argc) {
@@ -47,6 +48,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--frames")) { need(1); frames = std::atol(argv[++i]); }
         else if (!std::strcmp(argv[i], "--first-frame")) { need(1); first = std::atol(argv[++i]); }
         else if (!std::strcmp(argv[i], "--frame-stride")) { need(1); stride = std::atol(argv[++i]); }
+        else if (!std::strcmp(argv[i], "--rebuild-per-frame")) { rebuild = 1; }
         else if (!std::strcmp(argv[i], "--model")) { need(1); model = argv[++i]; }
         else if (!std::strcmp(argv[i], "--synthetic-mesh")) { need(2); nlon = std::atol(argv[++i]); nlat = std::atol(argv[++i]); }
         else {
@@ -68,6 +70,7 @@ int main(int argc, char** argv) {
         pth_scene_set_image(s, width > 0 ? (uint32_t)width : w0, height > 0 ? (uint32_t)height : h0, spp > 0 ? (uint32_t)spp : spp0,
                             depth > 0 ? (uint32_t)depth : depth0, bg);
     if (pth_scene_build(s) != 0) return fail("building the world");
+    if (pth_scene_set_rebuild_per_frame(s, rebuild) != 0) return fail("--rebuild-per-frame");
     mkdir(out.c_str(), 0777);  // main.rs expects ./output to exist; create it when it does not
     uint32_t total = 0, written = 0;
     double t_render = 0.0, t_write = 0.0;
@@ -77,6 +80,11 @@ int main(int argc, char** argv) {
         return fail("rendering");
     std::printf("%s: %u of %u frame(s) -> %s/image_%%04d.png; render %.3f s (%.1f Mrays/s), png %.3f s (overlapped)\n", name, written, total,
                 out.c_str(), t_render, t_render > 0 ? rays / t_render / 1e6 : 0.0, t_write);
+    if (rebuild) {
+        double t_build = 0.0, t_upload = 0.0;
+        pth_scene_rebuild_seconds(s, &t_build, &t_upload);
+        std::printf("%s: world rebuilt per frame: BvhNode::new %.3f s, flatten + upload %.3f s (not in the render time)\n", name, t_build, t_upload);
+    }
     pth_scene_destroy(s);
     return 0;
 }

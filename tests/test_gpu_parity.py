@@ -545,6 +545,14 @@ def test_frame_loop_writes_the_frames_render_returns(pt, tmp_path):
     for i in (1, 151):
         img, _ = s.render(0, i / 300.0, seed=3)
         assert np.array_equal(read_png(str(tmp_path / f"image_{i:04d}.png")), img)
+    # BASELINE.json configs[4]: the world rebuilt and uploaded before every frame (same seeds => the same frames), timed apart
+    again = tmp_path / "rebuilt"
+    again.mkdir()
+    info2 = s.render_frames(str(again), seed=3, first_frame=1, frame_stride=150, rebuild_per_frame=True)
+    assert info2["frames_written"] == 2 and info2["rays"] == info["rays"] and info2["seconds_build"] > 0 and info2["seconds_upload"] > 0
+    assert info["seconds_build"] == 0 and info["seconds_upload"] == 0
+    for i in (1, 151):
+        assert np.array_equal(read_png(str(again / f"image_{i:04d}.png")), read_png(str(tmp_path / f"image_{i:04d}.png")))
     # a static image has one frame
     c = pt.Scene("CornellBox").set_seeds(3, 3, 3).set_image(40, 30, 3, 6, (0, 0, 0)).build()
     info = c.render_frames(str(tmp_path / "."), seed=3)
@@ -558,6 +566,10 @@ def test_frame_loop_writes_the_frames_render_returns(pt, tmp_path):
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(read_png(str(out / "image_0000.png")), want)
+    r = subprocess.run([exe, "SphereField", "--width", "64", "--height", "36", "--spp", "4", "--depth", "8", "--seed", "3", "--out", str(out),
+                        "--first-frame", "151", "--frame-stride", "150", "--rebuild-per-frame"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "world rebuilt per frame" in r.stdout, r.stderr
+    assert np.array_equal(read_png(str(out / "image_0151.png")), read_png(str(tmp_path / "image_0151.png")))
     assert subprocess.run([exe, "NoSuchScene"], capture_output=True, timeout=60).returncode != 0
 
 
