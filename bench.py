@@ -216,7 +216,9 @@ def main():
         if ms_path > 0:
             # the fused kernel keeps the hit record in registers: it has to move 64 B per ray in and 64 B per survivor out
             kname, kms, kbytes, klaunches = "path_kernel", ms_path, shade_in * BYTES_PATH_IN + shade_out * BYTES_SHADE_OUT, n_path
-        elif ms_trace >= ms_shade:
+        # which of the two is the dominant kernel: by their times alone on the chip when that frame was measured (with several
+        # sub-passes sharing the chip a launch's duration also counts the time it waited for its share), else by the timed region
+        elif (iso.ms_trace >= iso.ms_shade) if iso is not None else (ms_trace >= ms_shade):
             kname, kms, kbytes, klaunches = "trace_kernel", ms_trace, rays * BYTES_TRACE, n_trace
         else:
             kname, kms, kbytes, klaunches = "shade_kernel", ms_shade, shade_in * BYTES_SHADE_IN + shade_out * BYTES_SHADE_OUT, n_shade

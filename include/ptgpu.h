@@ -152,8 +152,8 @@ const char* pt_last_error(const PtContext* ctx);
  * "repack_every" / "repack_first" (re-deal surviving rays over the waves every N bounces from bounce F on;
  *   default 0 = never / 8),
  * "lanes" (1..8: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
- *   trace overlaps another's shade; default 0 = automatic: 2, or 4 when the pass holds 3 * 2^27 paths or more), "lane_sync" (1 = lanes advance in lock step through events; default 0
- *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid; default 1),
+ *   trace overlaps another's shade; default 0 = automatic: 3), "lane_sync" (1 = lanes advance in lock step through events; default 0
+ *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid, 0 = its share of it; default 0),
  * "fused" (1 = scenes that take the lockstep walk and have only solid textures run the whole bounce loop of a sub-pass in one
  *   launch, each wave on its own region; 0 = one trace and one shade launch per bounce; default 0 -- the fused kernel needs 87
  *   VGPRs, runs 5 waves per SIMD instead of 8 and measures 10-15 % slower on the Cornell box; results are identical),

@@ -57,7 +57,7 @@ struct PtContext {
     Lane lanes[PT_MAX_LANES];
     int n_lanes = 0;  // 0 = chosen per call from the amount of work
     int lane_sync = 0;
-    int lane_full_grid = 1;
+    int lane_full_grid = 0;
 
     // options
     int64_t paths_per_pass = (int64_t)1 << 29;
@@ -781,10 +781,11 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     LaunchGeom geom = ctx->geom;
     auto lane_share = [](uint32_t total, int lanes, int l) { return total / (uint32_t)lanes + ((uint32_t)l < total % (uint32_t)lanes ? 1u : 0u); };
     for (;;) {  // a pass as large as allowed; when the device cannot hold its streams, half as large
-        // automatic: two overlapped sub-passes, four from 3 * 2^27 paths per pass on (measured on the Cornell box: 32-128 spp of
-        // 1080p are fastest with two, 256 spp with four)
+        // automatic: three overlapped sub-passes, each on a third of the persistent grid (measured on the Cornell box at 1080p,
+        // ms/frame at 32 / 64 / 128 / 256 spp: 20.5 / 37.3 / 70.4 / 133.3; two lanes on the full grid each: 21.0 / 38.0 / 72.4 /
+        // 138; four lanes on a quarter each: 20.8 / 37.5 / 70.4 / 133.7; four on the full grid: 22.2 / 38.9 / 73.7 / 136-141)
         uint32_t want = (uint32_t)ctx->n_lanes;
-        if (want == 0) want = (uint64_t)slots * npix >= ((uint64_t)3 << 27) ? 4u : 2u;
+        if (want == 0) want = 3u;
         n_lanes = (int)std::min<uint32_t>(want, slots);
         geom = ctx->geom;
         if (n_lanes > 1 && !ctx->lane_full_grid) geom.grid = std::max<uint32_t>(1u, ctx->geom.grid / (uint32_t)n_lanes);
