@@ -212,6 +212,10 @@ int pt_selftest_division(PtContext* ctx, const double* a, const double* b, size_
 int pt_selftest_rng(PtContext* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, double* out);
 /* Texture.value (texture.rs:5-7) of texture `tex` of the uploaded scene at n points (host arrays). */
 int pt_selftest_texture(PtContext* ctx, uint32_t tex, const double* points, size_t n, double* rgb_out);
+/* Host-only check of the guide-tree builder of the ordered walk ("trace_mode" 3): builds the tree over n >= 2 boxes
+ * (boxes[6*i .. 6*i+5] = lo.xyz, hi.xyz) and verifies that every box is a leaf exactly once and lies inside every box
+ * stored on the way down to it.  Touches no device.  PT_ERR_BAD_ARG for unusable boxes, PT_ERR_STATE for a broken tree. */
+int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth);
 
 #ifdef __cplusplus
 }

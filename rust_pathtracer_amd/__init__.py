@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     Scene,
     camera_new,
     write_png,
+    selftest_guide_tree,
     device_count,
     libptgpu,
     libpthost,

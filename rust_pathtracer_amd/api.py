@@ -181,6 +181,7 @@ _PTGPU_PROTOS = {
     "pt_selftest_division": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "pt_selftest_rng": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pt_selftest_texture": (C.c_int, [_vp, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "pt_selftest_guide_tree": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 _PTHOST_PROTOS = {
     "pth_last_error": (C.c_char_p, []),
@@ -240,6 +241,17 @@ def device_count() -> int:
     if n < 0:
         raise PtError(libptgpu.pt_last_error(None).decode())
     return n
+
+
+def selftest_guide_tree(boxes: np.ndarray):
+    """Builds and verifies the ordered walk's guide tree over boxes [n, 6] (lo.xyz, hi.xyz) on the host; returns (nodes, depth)."""
+    b = np.ascontiguousarray(boxes, dtype=np.float64)
+    assert b.ndim == 2 and b.shape[1] == 6
+    n_nodes, depth = C.c_uint32(), C.c_uint32()
+    rc = libptgpu.pt_selftest_guide_tree(b.ctypes.data, b.shape[0], C.byref(n_nodes), C.byref(depth))
+    if rc != 0:
+        raise PtError(f"pt_selftest_guide_tree: status {rc}")
+    return n_nodes.value, depth.value
 
 
 def write_png(path: str, rgb: np.ndarray):

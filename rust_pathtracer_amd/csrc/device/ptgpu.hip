@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -1096,6 +1097,57 @@ int pt_selftest_texture(PtContext* ctx, uint32_t tex, const double* points, size
     free_buf(dp);
     free_buf(dc);
     if (e != hipSuccess) return ctx->fail_hip("pt_selftest_texture", e);
+    return PT_OK;
+}
+
+// Host-only check of the guide-tree builder (guide_tree.h): builds the tree over n boxes (lo.xyz, hi.xyz each; box i stands for
+// the primitive record at stream offset 8 * i) and verifies it: every box is a leaf exactly once, every child box stored in a
+// node contains, after the outward rounding to f32, all the boxes below it.  No device is touched.
+int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth) {
+    if (!boxes || n < 2 || n > ((size_t)1 << 26)) return PT_ERR_BAD_ARG;
+    std::vector<GuideLeaf> leaves(n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { leaves[i].lo[k] = boxes[6 * i + k]; leaves[i].hi[k] = boxes[6 * i + 3 + k]; }
+        leaves[i].offset = (uint32_t)(8u * i);
+        guide::pad(leaves[i]);
+    }
+    std::vector<GuideNode> nodes;
+    if (!guide::build(leaves, nodes)) return PT_ERR_BAD_ARG;
+    if (nodes.size() != n - 1) return PT_ERR_STATE;
+    // depth-first: each entry carries the box its parent stored for it
+    struct Item { uint32_t ref; float box[6]; uint32_t depth; };
+    std::vector<Item> todo;
+    std::vector<uint8_t> seen_leaf(n, 0), seen_node(nodes.size(), 0);
+    const float inf = std::numeric_limits<float>::infinity();
+    todo.push_back({0u, {-inf, -inf, -inf, inf, inf, inf}, 1u});
+    uint32_t deepest = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        deepest = std::max(deepest, it.depth);
+        if (it.ref & PT_GUIDE_LEAF) {
+            const size_t i = (it.ref & ~PT_GUIDE_LEAF) / 8u;
+            if (i >= n || seen_leaf[i]) return PT_ERR_STATE;
+            seen_leaf[i] = 1;
+            for (int k = 0; k < 3; ++k)  // the box lies inside what the parent stored for it
+                if (!((double)it.box[k] <= boxes[6 * i + k] && (double)it.box[3 + k] >= boxes[6 * i + 3 + k])) return PT_ERR_STATE;
+            continue;
+        }
+        if (it.ref >= nodes.size() || seen_node[it.ref]) return PT_ERR_STATE;
+        seen_node[it.ref] = 1;
+        const GuideNode& nd = nodes[it.ref];
+        for (int c = 0; c < 2; ++c) {
+            Item ch{nd.child[c], {}, it.depth + 1u};
+            for (int k = 0; k < 6; ++k) ch.box[k] = nd.box[c][k];
+            for (int k = 0; k < 3; ++k)  // nested: a child's box never sticks out of its parent's
+                if (ch.box[k] < it.box[k] || ch.box[3 + k] > it.box[3 + k]) return PT_ERR_STATE;
+            todo.push_back(ch);
+        }
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (!seen_leaf[i]) return PT_ERR_STATE;
+    if (n_nodes) *n_nodes = (uint32_t)nodes.size();
+    if (max_depth) *max_depth = deepest;
     return PT_OK;
 }
 

@@ -282,3 +282,30 @@ def test_png_writer_round_trip(pt, tmp_path):
         assert np.array_equal(read_png(path), img)
     with pytest.raises(pt.PtError, match="could not create image file"):
         pt.write_png(str(tmp_path / "no_such_dir" / "a.png"), np.zeros((2, 2, 3), np.uint8))
+
+
+def test_guide_tree_builder(pt):
+    """The ordered walk's guide tree (guide_tree.h), built and verified on the host: every box a leaf exactly once, inside
+    every box stored above it -- for scattered boxes, flat ones (rectangles), many identical ones, a long thin row, and
+    huge next to tiny."""
+    rng = np.random.default_rng(4)
+    def boxes(lo, size):
+        return np.concatenate([lo, lo + size], axis=1)
+    n = 5000
+    cases = {
+        "scattered": boxes(rng.uniform(-100, 100, (n, 3)), rng.uniform(0.01, 5, (n, 3))),
+        "flat": boxes(rng.uniform(-10, 10, (n, 3)), rng.uniform(0, 2, (n, 3)) * (rng.integers(0, 3, (n, 1)) != np.arange(3))),
+        "identical": np.tile([[1.0, 2.0, 3.0, 1.5, 2.5, 3.5]], (777, 1)),
+        "row": boxes(np.stack([np.arange(n) * 1.0, np.zeros(n), np.zeros(n)], axis=1), np.full((n, 3), 0.5)),
+        "scales": boxes(rng.uniform(-1, 1, (n, 3)) * 10.0 ** rng.integers(-6, 6, (n, 1)), 10.0 ** rng.uniform(-8, 5, (n, 3))),
+        "two": np.array([[0, 0, 0, 1, 1, 1], [0, 0, 0, 1, 1, 1.0]]),
+    }
+    for name, b in cases.items():
+        nodes, depth = pt.selftest_guide_tree(b)
+        assert nodes == len(b) - 1, name
+        assert depth <= 64, (name, depth)
+    assert pt.selftest_guide_tree(cases["scattered"])[1] <= 30  # surface-area splits keep a scattered set shallow
+    for bad in (np.array([[0, 0, 0, 1, 1, np.inf], [0, 0, 0, 1, 1, 1.0]]), np.array([[0, 0, 0, 1, 1, 1.0]]),
+                np.array([[0, 0, 0, 1, 1, 1.0], [2, 0, 0, 1, 1, 1.0]]), np.array([[0, 0, 0, 1, 1, 1e38], [0, 0, 0, 1, 1, 1.0]])):
+        with pytest.raises(pt.PtError):
+            pt.selftest_guide_tree(bad)
