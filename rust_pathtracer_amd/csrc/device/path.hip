@@ -99,6 +99,9 @@ void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const P
 // loop on its own region in this one launch (trace its rays with the ordered wave loop, shade them, append the survivors,
 // next bounce): the pass then ends with the slowest WAVE, whose cost is a sum over its own few rays.
 // Same results bit for bit: the per-ray work is that of trace_ordered_kernel + shade_kernel.
+// (Tried: every LANE carrying its own path through the remaining bounces, shading whenever 16 lanes of the wave are ready --
+// no faster, 19.9 against 20.2 ms on the 8-spp mesh frame and equal at 64 spp: the tail is bound by the longest single PATH,
+// ~46 bounces x ~100 dependent fetches, not by lanes waiting for each other.)
 struct TailArgs {
     RayStream rays[2];
     uint4* state[2];
