@@ -32,7 +32,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(DevScene sc, PathArgs a)
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
     __shared__ __align__(16) uint8_t s_perlin[16];
     __shared__ uint2 s_exchange[PT_BLOCK]; // 64 slots per wave for the cooperative sampler
-    shade_stage_tables<false, TABLE_LDS>(sc, s_table, s_perlin);
+    shade_stage_tables<PT_PROC_NONE, TABLE_LDS>(sc, s_table, s_perlin);
     uint2* exchange = s_exchange + (threadIdx.x & ~63u);
     const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(DevScene sc, PathArgs a)
             traverse_walk(sc.walk, sc.walk_bytes, sc.walk_flags, live, o, d, 0.001, __builtin_huge_val(), t, prim); // ray.rs:25
             bool alive;
             V3 next_o, next_d;
-            shade_chunk<false, TABLE_LDS>(sc, env, s_table, s_perlin, false, exchange, live, st, o, d, t, prim, alive, next_o, next_d);
+            shade_chunk<PT_PROC_NONE, TABLE_LDS>(sc, env, s_table, s_perlin, false, exchange, live, st, o, d, t, prim, alive, next_o, next_d);
             if (!env.last_bounce) out_n += append_survivors(alive, out, state_out, region_base, out_n, next_o, next_d, st);
         }
         if (lane == 0) a.counts[(size_t)(bounce + 1u) * row + wave] = out_n;
@@ -115,10 +115,10 @@ struct TailArgs {
     OrderedScene os;
 };
 
-template <bool PROCEDURAL, bool TABLE_LDS>
+template <int PROCEDURAL, bool TABLE_LDS>
 __global__ __launch_bounds__(PT_BLOCK) void tail_kernel(DevScene sc, TailArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
-    __shared__ __align__(16) uint8_t s_perlin[PROCEDURAL ? PT_PERLIN_LDS_TABLES * 256 : 16];
+    __shared__ __align__(16) uint8_t s_perlin[shade_lds_aux_bytes<PROCEDURAL>()];
     __shared__ uint2 s_exchange[PT_BLOCK];
     __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
     const bool perlin_in_lds = shade_stage_tables<PROCEDURAL, TABLE_LDS>(sc, s_table, s_perlin);
@@ -191,11 +191,16 @@ void launch_tail(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const P
     a.env = make_shade_env(p, wf, first_bounce);
     a.os = OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes};
     const bool lds = sc.n_prims <= PT_SHADE_LDS_MAX_PRIMS;
-    if (sc.has_procedural) {
-        if (lds) hipLaunchKernelGGL((tail_kernel<true, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
-        else hipLaunchKernelGGL((tail_kernel<true, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+    // one instance per (texture kinds present, ShadePrim table in LDS or not)
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a); };
+    if (sc.has_procedural == PT_PROC_MARBLE) {
+        if (lds) launch(tail_kernel<PT_PROC_MARBLE, true>);
+        else launch(tail_kernel<PT_PROC_MARBLE, false>);
+    } else if (sc.has_procedural == PT_PROC_CHECKER) {
+        if (lds) launch(tail_kernel<PT_PROC_CHECKER, true>);
+        else launch(tail_kernel<PT_PROC_CHECKER, false>);
     } else {
-        if (lds) hipLaunchKernelGGL((tail_kernel<false, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
-        else hipLaunchKernelGGL((tail_kernel<false, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+        if (lds) launch(tail_kernel<PT_PROC_NONE, true>);
+        else launch(tail_kernel<PT_PROC_NONE, false>);
     }
 }

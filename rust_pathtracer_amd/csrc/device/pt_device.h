@@ -234,6 +234,7 @@ enum { PT_WK_NODE = 0, PT_WK_RECT_XY = 1, PT_WK_RECT_XZ = 2, PT_WK_RECT_YZ = 3, 
 #define PT_WALK_MAX_ITEMS 192 /* nodes + primitives: the stream stays within the scalar cache */
 #define PT_WALK_PLANES_IN_RANGE 1u /* walk_flags: see walk_division_is_proven */
 #define PT_WALK_BOXES_NESTED 2u    /* every node's box is finite and contains its child nodes' boxes (OrderedWalk) */
+enum { PT_PROC_NONE = 0, PT_PROC_CHECKER = 1, PT_PROC_MARBLE = 2 }; // (marble: with or without checkers)
 enum { PT_TRACE_LOCKSTEP = 0, PT_TRACE_STACK = 1, PT_TRACE_STREAM = 2, PT_TRACE_ORDERED = 3 };
 // Everything shade needs about the primitive it hit, in ONE 80-byte record (one dependent fetch instead of the
 // chain primitive -> material -> texture): the geometry the normal comes from, the material, and the colour
@@ -244,10 +245,10 @@ struct ShadePrim {
     uint32_t prim_type; // PT_PRIM_*
     uint32_t mat_type;  // PT_MAT_*
     uint32_t texture;   // texture index (procedural lookups)
-    uint32_t tex_solid; // 1: `color` below is the texture's value everywhere
+    uint32_t tex_solid; // 1: `color` is the texture's value everywhere; 2: a checker of two solid colours, `color` where the
+                        // sine product is not negative and `color_odd` where it is (texture.rs:36-45); 0: look the texture up
     float color[3];     // (f32 of the f64 colour: what the f32 radiometry multiplies by)
-    float pad0;
-    double pad1;
+    float color_odd[3];
 };
 static_assert(sizeof(ShadePrim) == 80, "ShadePrim must be 80 bytes");
 #define PT_SHADE_LDS_MAX_PRIMS 192
@@ -269,7 +270,7 @@ struct DevScene {
     uint32_t walk_bytes;
     uint32_t trace_mode; // PT_TRACE_*: which kernel walks it
     uint32_t walk_flags; // PT_WALK_*
-    uint32_t has_procedural; // any checker / marble texture
+    uint32_t has_procedural; // PT_PROC_*: which textures the scene has beyond solid colours
     const ShadePrim* shade_prims;
     const unsigned char* guide; // the guide tree of the ordered walk (guide_tree.h), node 0 = root; null when there is none
     uint32_t guide_nodes;
@@ -1084,18 +1085,44 @@ __device__ __forceinline__ double perlin_get(const uint8_t* perm, double px, dou
 }
 // Texture::value (texture.rs:19-23, :36-45, :75-80); u,v are unused by every texture the reference ships.
 #ifndef PT_TEXTURE_CALL
+// The sign of sin(a) without evaluating the sine: with k = rint(a / pi), a - k pi lies in about [-pi/2, pi/2] and
+// sin(a) = (-1)^k sin(a - k pi), so the sign is that of the reduced argument, flipped for odd k.  The reduction uses pi as
+// the sum of two doubles (106 bits) and two fused multiply-adds; for |a| <= 2^22 its error is below 1e-25, while no double
+// in that range comes closer than ~1e-19 to a multiple of pi: the sign is exact, i.e. the one any correct sin() returns
+// (the oracle's libm, the device's).  Outside [1e-100, 2^22] (zero, underflowing products, huge arguments) the caller
+// evaluates the sines.
+__device__ __forceinline__ bool sine_sign_is_cheap(double a) { return fabs(a) >= 1e-100 && fabs(a) <= 0x1p22; }
+__device__ __forceinline__ bool sine_is_negative(double a) {
+    const double k = rint(a * 0x1.45f306dc9c883p-2); // 1/pi
+    double r = __builtin_fma(-k, 0x1.921fb54442d18p+1, a);  // pi, rounded
+    r = __builtin_fma(-k, 0x1.1a62633145c07p-53, r);        // pi - the line above
+    const bool odd = ((int)k & 1) != 0;
+    return (r < 0.0) != odd;
+}
+// CheckerTexture::value's choice (texture.rs:36-45): sin(10 x) sin(10 y) sin(10 z) < 0 selects `odd`.  Only the SIGN of the
+// product is used: it comes from the reduced arguments unless a factor is zero, tiny or huge -- then the sines are evaluated
+// (behind a barrier the compiler cannot hoist them over: they are 40 times the work of the common path).
+__device__ __forceinline__ bool checker_is_odd(V3 p) {
+    const double ax = 10.0 * p.x, ay = 10.0 * p.y, az = 10.0 * p.z;
+    if (sine_sign_is_cheap(ax) && sine_sign_is_cheap(ay) && sine_sign_is_cheap(az))
+        return sine_is_negative(ax) != sine_is_negative(ay) != sine_is_negative(az); // no factor is zero, none underflows
+    double bx = ax, by = ay, bz = az;
+    asm volatile("; checker: the sines themselves" : "+v"(bx), "+v"(by), "+v"(bz));
+    return sin(bx) * sin(by) * sin(bz) < 0.0;
+}
 #define PT_TEXTURE_CALL __forceinline__
 #endif
+template <bool MARBLE>
 __device__ PT_TEXTURE_CALL V3 texture_value_procedural(const PtTexture* textures, uint32_t n_textures, const uint8_t* perlin,
                                                     uint32_t tex, V3 p) {
     for (uint32_t guard = 0; guard <= n_textures; ++guard) {
         const PtTexture* t = textures + tex;
         if (t->type == PT_TEX_CHECKER) {
-            double sines = sin(10.0 * p.x) * sin(10.0 * p.y) * sin(10.0 * p.z);
-            tex = (sines < 0.0) ? t->odd : t->even;
+            tex = checker_is_odd(p) ? t->odd : t->even;
             continue;
         }
         if (t->type == PT_TEX_SOLID) return v3(t->color[0], t->color[1], t->color[2]);
+        if (!MARBLE) return v3(0.0, 0.0, 0.0); // (the upload says there is none: the kernel carries neither the code nor its registers)
         // marble: texture.rs:60-80, 7 octaves
         const uint8_t* perm = perlin + (size_t)t->perlin_table * 256;
         double accumulator = 0.0, weight = 1.0;
@@ -1119,7 +1146,7 @@ template <bool PROCEDURAL>
 __device__ __forceinline__ V3 texture_value(const DevScene& sc, uint32_t tex, V3 p) {
     const PtTexture* t = sc.textures + tex;
     if (!PROCEDURAL || t->type == PT_TEX_SOLID) return v3(t->color[0], t->color[1], t->color[2]);
-    return texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, tex, p);
+    return texture_value_procedural<true>(sc.textures, sc.n_textures, sc.perlin, tex, p);
 }
 
 // ------------------------------------------------------------------ materials (material.rs)

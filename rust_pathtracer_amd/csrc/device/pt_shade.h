@@ -10,6 +10,14 @@
 #include "pt_launch.h"
 
 #define PT_PERLIN_LDS_TABLES 16
+#define PT_TEX_LDS_MAX 32
+// The block's auxiliary LDS area (`s_perlin` in the kernels): [Perlin permutation tables (marble only)][texture table]
+template <int PROCEDURAL>
+constexpr uint32_t shade_lds_perlin_bytes() { return PROCEDURAL == PT_PROC_MARBLE ? PT_PERLIN_LDS_TABLES * 256u : 0u; }
+template <int PROCEDURAL>
+constexpr uint32_t shade_lds_aux_bytes() {
+    return PROCEDURAL == PT_PROC_NONE ? 16u : shade_lds_perlin_bytes<PROCEDURAL>() + PT_TEX_LDS_MAX * (uint32_t)sizeof(PtTexture);
+}
 
 // What is the same for every ray of a bounce.
 struct ShadeEnv {
@@ -30,11 +38,12 @@ __device__ __forceinline__ void add_radiance(float4* plane, uint32_t path, float
     plane[path] = v;
 }
 
-// The block's LDS copies of the small tables shade reads per hit: the ShadePrim records (TABLE_LDS) and the Perlin
-// permutation tables (marble's seven octaves make 168 dependent byte look-ups each: from LDS, not from L2).
-template <bool PROCEDURAL, bool TABLE_LDS>
+// The block's LDS copies of the small tables shade reads per hit: the ShadePrim records (TABLE_LDS), the Perlin
+// permutation tables (marble's seven octaves make 168 dependent byte look-ups each: from LDS, not from L2) and the texture
+// table (a checker is two dependent look-ups, parent then child: TwoSpheres' shade 19.5 -> see profiles/README.md).
+template <int PROCEDURAL, bool TABLE_LDS>
 __device__ __forceinline__ bool shade_stage_tables(const DevScene& sc, unsigned char* s_table, uint8_t* s_perlin) {
-    const bool perlin_in_lds = PROCEDURAL && sc.n_perlin <= PT_PERLIN_LDS_TABLES;
+    const bool perlin_in_lds = PROCEDURAL == PT_PROC_MARBLE && sc.n_perlin <= PT_PERLIN_LDS_TABLES;
     if (TABLE_LDS) {
         const uint4* src = reinterpret_cast<const uint4*>(sc.shade_prims);
         uint4* dst = reinterpret_cast<uint4*>(s_table);
@@ -45,16 +54,23 @@ __device__ __forceinline__ bool shade_stage_tables(const DevScene& sc, unsigned 
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_perlin);
         for (uint32_t k = threadIdx.x; k < sc.n_perlin * 64u; k += PT_BLOCK) dst[k] = src[k];
     }
-    if (TABLE_LDS || perlin_in_lds) __syncthreads();
+    const bool textures_in_lds = PROCEDURAL != PT_PROC_NONE && sc.n_textures <= PT_TEX_LDS_MAX;
+    if (textures_in_lds) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.textures);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_perlin + shade_lds_perlin_bytes<PROCEDURAL>());
+        for (uint32_t k = threadIdx.x; k < sc.n_textures * (uint32_t)(sizeof(PtTexture) / 4u); k += PT_BLOCK) dst[k] = src[k];
+    }
+    if (TABLE_LDS || perlin_in_lds || textures_in_lds) __syncthreads();
     return perlin_in_lds;
 }
 
 // Shades the chunk's rays: lane `live` holds ray (o, d), its path state st and its hit (t, prim; prim < 0 = miss).
 // Returns, per lane, whether the path goes on (`alive`) with ray (next_o, next_d) and the updated state.
 // Must be called by all 64 lanes of the wave together (the unit-sphere sampler is a wave-level routine).
-// PROCEDURAL: the scene has checker / marble textures (else the kernel carries neither their code nor its registers).
+// PROCEDURAL (PT_PROC_*): the scene has checker / marble textures (the kernel carries only the code and registers of what it has:
+// 70 VGPRs for solid colours, 95 with checkers, 125 with marble).
 // TABLE_LDS: the ShadePrim table is small enough to be staged in LDS once per block.
-template <bool PROCEDURAL, bool TABLE_LDS>
+template <int PROCEDURAL, bool TABLE_LDS>
 __device__ __forceinline__ void shade_chunk(const DevScene& sc, const ShadeEnv& env, const unsigned char* s_table, const uint8_t* s_perlin,
                                             bool perlin_in_lds, uint2* exchange, bool live, uint4& st, V3 o, V3 d, double t, int32_t prim,
                                             bool& alive, V3& next_o, V3& next_d) {
@@ -95,9 +111,15 @@ __device__ __forceinline__ void shade_chunk(const DevScene& sc, const ShadeEnv& 
             // (Lambertian / Metal attenuation, material.rs:48-53,86-91; a Dielectric's is (1,1,1))
             if (emits || need_point) {
                 float cr = sp.color[0], cg = sp.color[1], cb = sp.color[2];
-                if (PROCEDURAL && !sp.tex_solid) {
-                    V3 c = perlin_in_lds ? texture_value_procedural(sc.textures, sc.n_textures, s_perlin, sp.texture, p)
-                                         : texture_value_procedural(sc.textures, sc.n_textures, sc.perlin, sp.texture, p);
+                if (PROCEDURAL && sp.tex_solid == 2u) { // a checker of two solid colours: no table look-ups
+                    if (checker_is_odd(p)) { cr = sp.color_odd[0]; cg = sp.color_odd[1]; cb = sp.color_odd[2]; }
+                } else if (PROCEDURAL && !sp.tex_solid) {
+                    constexpr bool marble = PROCEDURAL == PT_PROC_MARBLE;
+                    const PtTexture* textures = sc.n_textures <= PT_TEX_LDS_MAX
+                                                    ? reinterpret_cast<const PtTexture*>(s_perlin + shade_lds_perlin_bytes<PROCEDURAL>())
+                                                    : sc.textures;
+                    V3 c = perlin_in_lds ? texture_value_procedural<marble>(textures, sc.n_textures, s_perlin, sp.texture, p)
+                                         : texture_value_procedural<marble>(textures, sc.n_textures, sc.perlin, sp.texture, p);
                     cr = (float)c.x; cg = (float)c.y; cb = (float)c.z;
                 }
                 if (emits) {

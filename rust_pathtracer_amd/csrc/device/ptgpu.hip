@@ -483,6 +483,15 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
         if (m.type != PT_MAT_DIELECTRIC && s->textures[m.texture].type == PT_TEX_SOLID) {
             q.tex_solid = 1;
             for (int k = 0; k < 3; ++k) q.color[k] = (float)s->textures[m.texture].color[k];
+        } else if (m.type != PT_MAT_DIELECTRIC && s->textures[m.texture].type == PT_TEX_CHECKER) {
+            const PtTexture& ck = s->textures[m.texture];  // children in range: checked above
+            if (s->textures[ck.odd].type == PT_TEX_SOLID && s->textures[ck.even].type == PT_TEX_SOLID) {
+                q.tex_solid = 2;
+                for (int k = 0; k < 3; ++k) {
+                    q.color[k] = (float)s->textures[ck.even].color[k];
+                    q.color_odd[k] = (float)s->textures[ck.odd].color[k];
+                }
+            }
         }
     }
 
@@ -667,9 +676,11 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds
     sc.walk_flags = walk_flags;
     sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
-    sc.has_procedural = 0;
-    for (uint32_t i = 0; i < s->n_textures; ++i)
-        if (s->textures[i].type != PT_TEX_SOLID) sc.has_procedural = 1;
+    sc.has_procedural = PT_PROC_NONE;
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        if (s->textures[i].type == PT_TEX_CHECKER && sc.has_procedural == PT_PROC_NONE) sc.has_procedural = PT_PROC_CHECKER;
+        if (s->textures[i].type == PT_TEX_PERLIN) sc.has_procedural = PT_PROC_MARBLE;
+    }
 
     // LDS plan for the trace kernel: [staged nodes][staged primitives][per-lane stack]
     const size_t stack_bytes = (size_t)sc.stack_depth * PT_BLOCK * sizeof(uint32_t);

@@ -10,6 +10,13 @@
 // Reads 76 B/ray (ray 48, hit 12, state 16), writes 64 B per surviving ray (ray 48, state 16).
 #include "pt_shade.h"
 
+#ifndef PT_SHADE_WAVES_CHECKER
+#define PT_SHADE_WAVES_CHECKER 5
+#endif
+#ifndef PT_SHADE_WAVES_MARBLE
+#define PT_SHADE_WAVES_MARBLE 4
+#endif
+
 struct ShadeArgs {
     RayStream in, out;
     const uint4* state_in;
@@ -22,10 +29,11 @@ struct ShadeArgs {
     ShadeEnv env;
 };
 
-template <bool PROCEDURAL, bool TABLE_LDS>
-__global__ __launch_bounds__(PT_BLOCK) void shade_kernel(DevScene sc, ShadeArgs a) {
+template <int PROCEDURAL, bool TABLE_LDS>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PROCEDURAL == PT_PROC_CHECKER ? PT_SHADE_WAVES_CHECKER : (PROCEDURAL == PT_PROC_MARBLE ? PT_SHADE_WAVES_MARBLE : 1))))
+void shade_kernel(DevScene sc, ShadeArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
-    __shared__ __align__(16) uint8_t s_perlin[PROCEDURAL ? PT_PERLIN_LDS_TABLES * 256 : 16];
+    __shared__ __align__(16) uint8_t s_perlin[shade_lds_aux_bytes<PROCEDURAL>()];
     __shared__ uint2 s_exchange[PT_BLOCK]; // 64 slots per wave for the cooperative sampler
     const bool perlin_in_lds = shade_stage_tables<PROCEDURAL, TABLE_LDS>(sc, s_table, s_perlin);
     uint2* exchange = s_exchange + (threadIdx.x & ~63u);
@@ -89,12 +97,17 @@ void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
     a.n_waves = wf.n_waves;
     a.env = make_shade_env(p, wf, bounce);
     const bool lds = sc.n_prims <= PT_SHADE_LDS_MAX_PRIMS;
-    if (sc.has_procedural) {
-        if (lds) hipLaunchKernelGGL((shade_kernel<true, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
-        else hipLaunchKernelGGL((shade_kernel<true, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+    // one instance per (texture kinds present, ShadePrim table in LDS or not)
+    auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a); };
+    if (sc.has_procedural == PT_PROC_MARBLE) {
+        if (lds) launch(shade_kernel<PT_PROC_MARBLE, true>);
+        else launch(shade_kernel<PT_PROC_MARBLE, false>);
+    } else if (sc.has_procedural == PT_PROC_CHECKER) {
+        if (lds) launch(shade_kernel<PT_PROC_CHECKER, true>);
+        else launch(shade_kernel<PT_PROC_CHECKER, false>);
     } else {
-        if (lds) hipLaunchKernelGGL((shade_kernel<false, true>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
-        else hipLaunchKernelGGL((shade_kernel<false, false>), dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
+        if (lds) launch(shade_kernel<PT_PROC_NONE, true>);
+        else launch(shade_kernel<PT_PROC_NONE, false>);
     }
 }
 

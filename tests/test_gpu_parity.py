@@ -294,10 +294,19 @@ def test_texture_values_match_oracle(gpu_ctx, pt, oracle):
     types = [d.textures[i].type for i in range(d.n_textures)]
     rng = np.random.default_rng(5)
     pts = np.concatenate([rng.uniform(-12, 12, (20000, 3)), rng.uniform(-1000, 1000, (20000, 3))])
-    got = gpu_ctx.selftest_texture(types.index(api.TEX_CHECKER), pts)
-    want = oracle.texture_value(0, 0.0, 0, pts)
-    # a checker flips colour where the sine product crosses 0: allow the few points within an ulp of a boundary
-    assert (np.abs(got - want).max(axis=1) > 0).mean() < 1e-4
+    # the checker needs only the sign of each sine, which the device takes from the reduced argument (pt_device.h
+    # sine_is_negative): exact, so not one point may differ -- also not the doubles next to a zero of sin(10 x), coordinates
+    # that are zero, tiny or huge (where the device evaluates the sines), and the far ground of the scaled mesh scene
+    k = rng.integers(-400000, 400000, (30000, 3)).astype(np.float64)
+    near_zero_of_sine = k * np.pi / 10.0
+    for _ in range(3):
+        near_zero_of_sine = np.concatenate([near_zero_of_sine, np.nextafter(near_zero_of_sine[:30000], np.inf), np.nextafter(near_zero_of_sine[:30000], -np.inf)])
+    special = rng.choice(np.array([0.0, -0.0, 5e-324, 1e-200, -1e-150, 1e-101, 1e-99, 0.1 * np.pi, 419430.3, 419430.5, -5e5, 1e9, -3e15, 1e300]), (20000, 3))
+    special[::2, 0] = rng.uniform(-5, 5, 10000)
+    checker_pts = np.concatenate([pts, near_zero_of_sine, special, rng.uniform(-1e5, 1e5, (40000, 3))])
+    got = gpu_ctx.selftest_texture(types.index(api.TEX_CHECKER), checker_pts)
+    want = oracle.texture_value(0, 0.0, 0, checker_pts)
+    assert np.array_equal(got, want), f"{(np.abs(got - want).max(axis=1) > 0).sum()} checker colours differ"
     got = gpu_ctx.selftest_texture(types.index(api.TEX_PERLIN), pts)
     want = oracle.texture_value(1, 4.0, 9, pts)
     assert np.abs(got - want).max() < 1e-9  # sin of an argument up to ~4e3 evaluated by two libms
