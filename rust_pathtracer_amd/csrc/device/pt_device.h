@@ -854,10 +854,10 @@ struct OrderedWalk {
             off = ref & ~PT_GUIDE_LEAF;
             mode = leaf ? PT_OW_LEAF : PT_OW_GUIDE;
             cur = leaf ? off : cur;
-        } else if (!literal && w.best_prim < 0) {
-            mode = PT_OW_IDLE;
+        } else if (!literal && w.best_prim < 0 && second_t == __builtin_huge_val()) {
+            mode = PT_OW_IDLE; // no primitive test reported anything
             off = 0;
-        } else if (literal || second_t <= near(w.best_t)) {
+        } else if (literal || !(second_t > near(w.best_t))) {
             mode = PT_OW_LITERAL; // StreamWalk::begin without recomputing the reciprocals; the root record is a node (kind word 0)
             w.best_t = t_max;
             w.best_prim = -1;
@@ -893,10 +893,15 @@ struct OrderedWalk {
         w.steps_nodes = w.steps_leaves = 0;
         steps_guide = steps_leaf = steps_verify = went_literal = 0;
 #endif
-        // the guide's slab arithmetic and the nesting argument assume finite, nonzero reciprocals and a finite origin
-        const bool ordinary = fabs(w.inv.x) <= 0x1p1000 && fabs(w.inv.y) <= 0x1p1000 && fabs(w.inv.z) <= 0x1p1000 && fabs(w.inv.x) >= 0x1p-1000 &&
-                              fabs(w.inv.y) >= 0x1p-1000 && fabs(w.inv.z) >= 0x1p-1000 && fabs(o.x) <= 0x1p1000 && fabs(o.y) <= 0x1p1000 &&
-                              fabs(o.z) <= 0x1p1000 && t_min == t_min && t_max_ == t_max_;
+        // Ordinary rays only: direction components in [2^-100, 2^100], origin within 2^100.  Then (with the scene's
+        // coordinates finite and below 1e37, checked at upload) no primitive test and no box test can overflow or produce
+        // a NaN, which is what the guide's arithmetic, the nesting argument AND the premise "a primitive that reports a
+        // hit is crossed inside its box" rest on: the reference accepts a sphere whose discriminant is inf - inf = NaN
+        // (geometry.rs:132-148: every comparison with NaN is false) wherever the ray is, and a NaN bound then lets any
+        // later hit replace a nearer one.  Such rays take the literal walk.
+        const bool ordinary = fabs(w.inv.x) <= 0x1p100 && fabs(w.inv.y) <= 0x1p100 && fabs(w.inv.z) <= 0x1p100 && fabs(w.inv.x) >= 0x1p-100 &&
+                              fabs(w.inv.y) >= 0x1p-100 && fabs(w.inv.z) >= 0x1p-100 && fabs(o.x) <= 0x1p100 && fabs(o.y) <= 0x1p100 &&
+                              fabs(o.z) <= 0x1p100 && t_min == t_min && t_max_ == t_max_;
         advance(sc, nullptr, ordinary, 0u, !ordinary);
     }
     // one child's box against the ray: entry and exit parameters, each moved outwards by 1e-9 of itself
@@ -937,7 +942,9 @@ struct OrderedWalk {
     // a candidate from a primitive test run with the bound near(best)
     __device__ __forceinline__ void consider(bool hit, double t, uint32_t prim, uint32_t link) {
         if (!hit) return;
-        if (t < w.best_t || w.best_prim < 0) {
+        if (t != t) { // cannot happen for an ordinary ray (see begin); if it does, the literal walk decides
+            second_t = -__builtin_huge_val();
+        } else if (t < w.best_t || w.best_prim < 0) {
             if (w.best_prim >= 0) second_t = fmin(second_t, w.best_t);
             w.best_t = t; w.best_prim = (int32_t)prim; best_parent = link;
         } else {

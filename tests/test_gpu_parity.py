@@ -250,12 +250,18 @@ def _box_world(tiny_plane):
     return ps, os_
 
 
+@pytest.mark.parametrize("mode", [-1, 2, 3])
 @pytest.mark.parametrize("tiny_plane", [False, True])
-def test_trace_extreme_magnitudes(gpu_ctx, oracle, tiny_plane):
-    """Rays whose coordinates leave the range in which the walk's shortcuts are proven (reciprocal quotients, NaN-free
-    box test) must come out exactly like ordinary ones: whole waves of them, and single ones salted into ordinary waves."""
+def test_trace_extreme_magnitudes(gpu_ctx, oracle, tiny_plane, mode):
+    """Rays whose coordinates leave the range in which the walks' shortcuts are proven (the lockstep walk's reciprocal
+    quotients and NaN-free box test; the ordered walk's guide-tree arithmetic and nesting argument) must come out exactly
+    like ordinary ones: whole waves of them, and single ones salted into ordinary waves."""
     s, o = _box_world(tiny_plane)
-    gpu_ctx.upload(s)
+    gpu_ctx.set_option("trace_mode", mode)
+    try:
+        gpu_ctx.upload(s)
+    finally:
+        gpu_ctx.set_option("trace_mode", -1)
     rng = np.random.default_rng(11)
     n = 64 * 400
     ro = rng.uniform(-4, 4, (n, 3))
