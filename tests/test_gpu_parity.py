@@ -159,6 +159,30 @@ def test_every_trace_kernel_gives_the_same_hits(gpu_ctx, oracle, mode):
         gpu_ctx.set_option("trace_mode", -1)
 
 
+@pytest.mark.parametrize("seed", [10, 11, 12, 13, 14, 15, 16, 17])
+def test_ordered_walk_fuzz(gpu_ctx, oracle, seed):
+    """The ordered walk forced onto random worlds of every size (a handful of objects to a few hundred primitives, every
+    primitive kind, hollow spheres, meshes), with rays from outside, from inside the objects and from their surfaces, and
+    windows that allow hits behind the origin: bit-exact against the oracle."""
+    rng = np.random.default_rng(seed)
+    n_objects = int(rng.choice([3, 8, 30, 90]))
+    s, o = su.random_world(seed, n_objects=n_objects, with_mesh=bool(seed % 2), extent=float(rng.choice([2.0, 10.0, 300.0])))
+    try:
+        gpu_ctx.set_option("trace_mode", 3)
+        gpu_ctx.upload(s)
+    finally:
+        gpu_ctx.set_option("trace_mode", -1)
+    ext = 10.0
+    ro, rd = su.random_rays(seed + 100, 30000)
+    inside_o = rng.uniform(-ext, ext, (20000, 3))
+    inside_d = rng.normal(size=(20000, 3)) * 10.0 ** rng.uniform(-3, 3, (20000, 1))
+    p2, d2 = su.bounce_rays(o, ro, rd, seed + 200)
+    ro, rd = np.concatenate([ro, inside_o, p2]), np.concatenate([rd, inside_d, d2])
+    for t_min, t_max in [(0.001, np.inf), (-3.0, 3.0), (-np.inf, np.inf), (0.0, 1e-3), (-1e-9, 1e9)]:
+        prim, t, normal, front = o.trace(ro, rd, t_min, t_max)
+        assert_hits_equal(gpu_ctx.trace_batch(ro, rd, t_min, t_max), prim, t, normal, front)
+
+
 def _tie_world(bvh_seed):
     """Primitives that meet exactly: a grid of unit boxes sharing faces, a floor in the plane of their bottoms, a sheet in
     the plane of their tops, the same sphere three times, touching spheres, a fan of triangles around one apex (both
