@@ -115,8 +115,15 @@ struct TailArgs {
     OrderedScene os;
 };
 
+#ifndef PT_TAIL_WAVES
+#define PT_TAIL_WAVES 6
+#endif
 template <int PROCEDURAL, bool TABLE_LDS>
-__global__ __launch_bounds__(PT_BLOCK) void tail_kernel(DevScene sc, TailArgs a) {
+// (The persistent grid of an ordered-walk scene is 6 blocks per CU; a tail kernel of which only 4 fit runs them in two rounds,
+// i.e. twice the longest path.  Where LDS allows -- tables in global memory, no marble -- the kernel is therefore held to 80
+// VGPRs, spilling a few dozen rarely-used values: 1M-triangle mesh, 64 spp: 54.2 -> 49.4 ms/frame.)
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu((TABLE_LDS || PROCEDURAL == PT_PROC_MARBLE) ? 1 : PT_TAIL_WAVES)))
+void tail_kernel(DevScene sc, TailArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
     __shared__ __align__(16) uint8_t s_perlin[shade_lds_aux_bytes<PROCEDURAL>()];
     __shared__ uint2 s_exchange[PT_BLOCK];

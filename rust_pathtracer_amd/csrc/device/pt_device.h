@@ -812,7 +812,7 @@ struct StreamWalk {
 //      component and when the guide stack overflows.
 // Correctness never rests on the guide tree being good, only on its boxes containing their primitives.
 #define PT_GUIDE_LEAF 0x80000000u
-#define PT_GUIDE_STACK 24
+#define PT_GUIDE_STACK 20 /* 20 KB of LDS per block: six blocks of the tail kernel (path.hip) fit a CU; deeper => literal walk */
 enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4 };
 struct OrderedScene { // wave-uniform: what the ordered walk reads
     const unsigned char* guide;  // guide tree: guide_nodes records of 64 bytes, node 0 = root
