@@ -13,6 +13,9 @@
 #ifndef PT_SHADE_WAVES_CHECKER
 #define PT_SHADE_WAVES_CHECKER 5
 #endif
+#ifndef PT_SHADE_WAVES_SOLID
+#define PT_SHADE_WAVES_SOLID 1
+#endif
 #ifndef PT_SHADE_WAVES_MARBLE
 #define PT_SHADE_WAVES_MARBLE 4
 #endif
@@ -30,7 +33,7 @@ struct ShadeArgs {
 };
 
 template <int PROCEDURAL, bool TABLE_LDS>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PROCEDURAL == PT_PROC_CHECKER ? PT_SHADE_WAVES_CHECKER : (PROCEDURAL == PT_PROC_MARBLE ? PT_SHADE_WAVES_MARBLE : 1))))
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PROCEDURAL == PT_PROC_CHECKER ? PT_SHADE_WAVES_CHECKER : (PROCEDURAL == PT_PROC_MARBLE ? PT_SHADE_WAVES_MARBLE : PT_SHADE_WAVES_SOLID))))
 void shade_kernel(DevScene sc, ShadeArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
     __shared__ __align__(16) uint8_t s_perlin[shade_lds_aux_bytes<PROCEDURAL>()];
