@@ -162,8 +162,10 @@ const char* pt_last_error(const PtContext* ctx);
  *   walk of the record stream, 3 = ordered walk: nearest-first over a surface-area guide tree built at upload, then a
  *   proof per ray that the reference's walk returns the same primitive, else the walk of mode 2 for that ray; falls back
  *   to 2 when the scene's boxes are not finite and nested; all four give identical results),
- * "tail_from" (ordered walk: bounces from this one on run in ONE launch per sub-pass, each wave looping over its own
- *   rays; -1 = automatic: 4 for scenes of 65536 primitives or more, never otherwise; results are identical),
+ * "tail_from" (bounces from this one on run in ONE launch per sub-pass, each wave looping over its own rays -- for scenes
+ *   on the ordered walk, and for scenes on the lockstep walk with solid textures ("fused" = from bounce 0); -1 = automatic:
+ *   4 for ordered-walk scenes of 65536 primitives or more, never otherwise (measured on the Cornell box: 20.5 / 21.3 / 22.2 ms
+ *   per 32-spp frame for never / 16 / 12); results are identical),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 

@@ -1,4 +1,5 @@
-// path.hip -- the whole bounce loop of a pass in ONE launch, for scenes that take the wave-uniform walk.
+// path.hip -- the bounce loop of a pass from some bounce on in ONE launch, each wave on its own region.
+// First the version for scenes that take the wave-uniform walk (options "fused": from bounce 0; "tail_from": from a later one).
 //
 // Wave-private regions (pt_launch.h) mean that a wave never needs anything another wave produced: its rays stay in its
 // own region through every bounce.  So the wave runs Ray::color's loop (ray.rs:20-41) by itself,
@@ -21,9 +22,11 @@
 struct PathArgs {
     RayStream rays[2];
     uint4* state[2];
-    uint32_t* counts; // rows of n_waves + 1 words; row 0 comes from raygen, rows 1.. must be zero on entry
+    const uint32_t* counts_in; // the row of first_bounce (raygen's, or the preceding shade launch's)
+    uint32_t* counts;          // all rows (n_waves + 1 words each); rows first_bounce + 1 .. max_bounces are written here
     uint32_t n_waves;
-    uint32_t max_bounces;
+    uint32_t first_bounce, max_bounces;
+    int first_buf;             // which ping-pong buffer holds first_bounce's rays
     ShadeEnv env;     // stream and last_bounce are set per bounce by the kernel
 };
 
@@ -37,14 +40,15 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(DevScene sc, PathArgs a)
     const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t row = a.n_waves + 1u;
-    uint32_t n = __builtin_amdgcn_readfirstlane(a.counts[wave]);
-    const uint32_t region = a.counts[a.n_waves];
+    uint32_t n = __builtin_amdgcn_readfirstlane(a.counts_in[wave]);
+    const uint32_t region = a.counts_in[a.n_waves];
     const size_t region_base = (size_t)wave * region;
     ShadeEnv env = a.env;
-    for (uint32_t bounce = 0; bounce < a.max_bounces && n != 0u; ++bounce) {
+    uint32_t bounce = a.first_bounce;
+    for (; bounce < a.max_bounces && n != 0u; ++bounce) {
         env.stream = bounce + 1u;
         env.last_bounce = bounce + 1u >= a.max_bounces;
-        const bool odd = bounce & 1u;
+        const bool odd = ((bounce - a.first_bounce) & 1u) != (uint32_t)a.first_buf;
         const RayStream in = odd ? a.rays[1] : a.rays[0], out = odd ? a.rays[0] : a.rays[1];
         const uint4* state_in = odd ? a.state[1] : a.state[0];
         uint4* state_out = odd ? a.state[0] : a.state[1];
@@ -72,22 +76,30 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(DevScene sc, PathArgs a)
             if (!env.last_bounce) out_n += append_survivors(alive, out, state_out, region_base, out_n, next_o, next_d, st);
         }
         if (lane == 0) a.counts[(size_t)(bounce + 1u) * row + wave] = out_n;
+        if (wave == 0 && lane == 0) a.counts[(size_t)(bounce + 1u) * row + a.n_waves] = region;
         // the wave's own stores (survivors, radiance sums) before its loads of the next bounce: same CU, same L1
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         n = out_n;
     }
+    // rows this wave never reached (it ran out of rays): zero, as the stand-alone shade kernel would have written
+    for (uint32_t b = bounce + 1u; b <= a.max_bounces; ++b)
+        if (lane == 0) a.counts[(size_t)b * row + wave] = 0u;
 }
 
-void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf) {
+void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf, const BounceIO& io,
+                 uint32_t first_bounce) {
     PathArgs a;
     a.rays[0] = wf.rays[0];
     a.rays[1] = wf.rays[1];
     a.state[0] = wf.state[0];
     a.state[1] = wf.state[1];
+    a.counts_in = io.counts_in;
     a.counts = wf.counts;
     a.n_waves = wf.n_waves;
+    a.first_bounce = first_bounce;
     a.max_bounces = p.max_bounces;
-    a.env = make_shade_env(p, wf, 0);
+    a.first_buf = io.in;
+    a.env = make_shade_env(p, wf, first_bounce);
     if (sc.n_prims <= PT_SHADE_LDS_MAX_PRIMS) hipLaunchKernelGGL(path_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
     else hipLaunchKernelGGL(path_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a);
 }

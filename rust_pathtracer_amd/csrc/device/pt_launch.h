@@ -55,7 +55,8 @@ void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
 void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf,
                   const BounceIO& io, uint32_t bounce);
 // The whole bounce loop in one launch (path.hip); the count rows 1.. of wf.counts must have been zeroed.
-void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf);
+void launch_path(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf, const BounceIO& io,
+                 uint32_t first_bounce);
 // Bounces first_bounce.. of the pass in one launch, each wave on its own region (ordered walk only); io.in / io.counts_in: where
 // first_bounce's rays and counts are.
 void launch_tail(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const PassParams& p, const Wavefront& wf, const BounceIO& io,

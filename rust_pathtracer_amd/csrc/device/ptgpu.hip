@@ -13,6 +13,9 @@
 #ifndef PT_TAIL_FROM_DEFAULT
 #define PT_TAIL_FROM_DEFAULT 4u
 #endif
+#ifndef PT_TAIL_FROM_LOCKSTEP
+#define PT_TAIL_FROM_LOCKSTEP 4096u /* lockstep scenes: never, unless "tail_from" says so */
+#endif
 #ifndef PT_TAIL_MIN_PRIMS
 #define PT_TAIL_MIN_PRIMS 65536u
 #endif
@@ -834,6 +837,13 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         if (ctx->tail_from >= 0) tail_from = (uint32_t)ctx->tail_from;
         else if (ctx->sc.n_prims >= PT_TAIL_MIN_PRIMS) tail_from = PT_TAIL_FROM_DEFAULT;
     }
+    // lockstep walk, solid textures: the same idea with path.hip's fused kernel ("fused" = from bounce 0)
+    const bool lockstep_tail_ok = ctx->sc.trace_mode == PT_TRACE_LOCKSTEP && ctx->sc.has_procedural == PT_PROC_NONE && ctx->repack_every == 0;
+    if (lockstep_tail_ok) {
+        if (fused) tail_from = 0;
+        else if (ctx->tail_from >= 0) tail_from = (uint32_t)ctx->tail_from;
+        else tail_from = PT_TAIL_FROM_LOCKSTEP;
+    }
     struct Timed { int kind; size_t start, stop; };
     std::vector<Timed> timed;
     size_t ev_used = 0;
@@ -861,10 +871,9 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         pl.steps.push_back({K_RAYGEN, 0, BounceIO{0, 1, nullptr, nullptr}});
         int buf = 0;
         const uint32_t* counts_in = wf.counts;
-        if (fused) pl.steps.push_back({K_PATH, 0, BounceIO{0, 1, nullptr, nullptr}});
-        for (uint32_t b = 0; b < max_bounces && !fused; ++b) {
+        for (uint32_t b = 0; b < max_bounces; ++b) {
             if (b == tail_from) {
-                pl.steps.push_back({K_TAIL, b, BounceIO{buf, buf ^ 1, counts_in, nullptr}});
+                pl.steps.push_back({lockstep_tail_ok ? K_PATH : K_TAIL, b, BounceIO{buf, buf ^ 1, counts_in, nullptr}});
                 break;
             }
             BounceIO io{buf, buf ^ 1, counts_in, wf.counts + count_row(wf, b + 1)};
@@ -928,12 +937,8 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                 PT_HIP(ctx, new_event(t.stop));
                 PT_HIP(ctx, hipEventRecord(ctx->events[t.start], ln.stream));
                 switch (st.kind) {
-                    case K_RAYGEN:
-                        if (fused)  // waves that run out of rays leave the rest of their count column untouched
-                            PT_HIP(ctx, hipMemsetAsync(ln.wf.counts, 0, (size_t)n_counts * (ln.wf.n_waves + 1u) * sizeof(uint32_t), ln.stream));
-                        launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf);
-                        break;
-                    case K_PATH: launch_path(ln.stream, geom, ctx->sc, plan[l].p, ln.wf); ++launches_path; break;
+                    case K_RAYGEN: launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf); break;
+                    case K_PATH: launch_path(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_path; break;
                     case K_TAIL: launch_tail(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_path; break;
                     case K_TRACE: launch_trace(ln.stream, geom, ctx->sc, ln.wf, st.io); ++launches_trace; break;
                     case K_SHADE: launch_shade(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_shade; break;

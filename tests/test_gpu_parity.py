@@ -452,9 +452,9 @@ def test_scheduling_options_do_not_change_results(gpu_ctx, pt, oracle):
         for opts in [dict(lanes=1), dict(lanes=2), dict(lanes=4), dict(lanes=2, lane_sync=1, lane_full_grid=1), dict(lanes=0),
                      dict(lanes=1, repack_every=1, repack_first=1), dict(lanes=3, repack_every=3, repack_first=2, blocks_per_cu=3),
                      dict(lanes=2, paths_per_pass=w * h * 4), dict(lanes=1, fused=1), dict(lanes=2, fused=1, blocks_per_cu=5),
-                     dict(lanes=2, fused=1, paths_per_pass=w * h * 2)]:
+                     dict(lanes=2, fused=1, paths_per_pass=w * h * 2), dict(lanes=3, tail_from=7), dict(lanes=1, tail_from=1), dict(lanes=2, tail_from=depth - 1)]:
             defaults = dict(lanes=2, lane_sync=0, lane_full_grid=0, repack_every=0, repack_first=8, blocks_per_cu=0,
-                            paths_per_pass=1 << 29, fused=0)
+                            paths_per_pass=1 << 29, fused=0, tail_from=-1)
             for k, v in {**defaults, **opts}.items():
                 ctx.set_option(k, v)
             s, o = su.named_pair("CornellBox", 1, 1, 1, image=(w, h, spp, depth, (0, 0, 0)))
