@@ -309,3 +309,22 @@ def test_guide_tree_builder(pt):
                 np.array([[0, 0, 0, 1, 1, 1.0], [2, 0, 0, 1, 1, 1.0]]), np.array([[0, 0, 0, 1, 1, 1e38], [0, 0, 0, 1, 1, 1.0]])):
         with pytest.raises(pt.PtError):
             pt.selftest_guide_tree(bad)
+
+
+def test_obj_reader_edge_cases(pt, tmp_path):
+    """CRLF line ends, comments, negative (relative) indices, a five-sided face (fan of three), v/vt/vn and v//vn and bare
+    references in one file, a group statement starting a new model."""
+    (tmp_path / "e.obj").write_bytes(
+        b"mtllib e.mtl\r\n# comment\r\no first\r\nv 0 0 0\r\nv 1 0 0\r\nv 1 1 0\r\nv 0 1 0\r\nv 0.5 1.5 0\r\nvn 0 0 1\r\nvt 0 0\r\n"
+        b"usemtl glass\r\nf -5/1/1 -4/1/1 -3/1/1 -2/1/1 -1/1/1\r\ng grp\r\nf 1//1 2//1 3//1\r\nf 1 2 4\r\n")
+    (tmp_path / "e.mtl").write_text("newmtl glass\nillum 7\nNi 1.5\nKd 1 1 1\n")
+    nm, nt, nl = C.c_uint32(), C.c_uint64(), C.c_uint32()
+    assert pt.libpthost.pth_obj_probe(str(tmp_path / "e.obj").encode(), C.byref(nm), C.byref(nt), C.byref(nl)) == 0
+    assert (nm.value, nt.value, nl.value) == (2, 5, 1)
+    s = pt.Scene("ModelTest").set_model_path(str(tmp_path / "e.obj")).build()
+    meshes = s.meshes()
+    assert np.ctypeslib.as_array(meshes[0].indices, shape=(9,)).tolist() == [0, 1, 2, 0, 2, 3, 0, 3, 4]  # -5..-1 = vertices 1..5, fanned
+    assert np.ctypeslib.as_array(meshes[0].positions, shape=(15,)).tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0, 0, 1, 0, 0.5, 1.5, 0]
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(pt.PtError):
+        pt.Scene("ModelTest").set_model_path(str(tmp_path / "bad.obj"))
