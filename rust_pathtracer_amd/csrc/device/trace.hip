@@ -133,7 +133,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
     }
 }
 
-__global__ __launch_bounds__(PT_BLOCK) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
+#ifndef PT_ORDERED_WAVES
+#define PT_ORDERED_WAVES 1
+#endif
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_ORDERED_WAVES))) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
                                                                  uint32_t n_waves, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
     __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
     const uint32_t wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
