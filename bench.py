@@ -210,6 +210,7 @@ def main():
         rays_total = rays
 
     if rank == 0:
+        headline = (args.scene, w, h, spp, depth) == ("CornellBox", 1920, 1080, 256, 50)
         ms_per_step = elapsed / args.steps * 1e3
         mrays = rays_total / elapsed / 1e6
         # roofline of the dominant kernel on rank 0, from HIP-event times on the library's stream
@@ -251,7 +252,7 @@ def main():
                                                "shade": round(iso.ms_shade, 3), "fold": round(iso.ms_fold, 3), "path": round(iso.ms_path, 3)},
                         "note": "one untimed frame with lanes=1 (no overlap between sub-passes)"}
         out = {
-            "metric": "Mrays/s (ray segments = hit queries per second), CornellBox 1080p 256spp; ms_per_step = s/frame*1e3",
+            "metric": f"Mrays/s (ray segments = hit queries per second), {args.scene} {h}p {spp}spp; ms_per_step = s/frame*1e3",
             "value": round(mrays, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -263,7 +264,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64 geometry / f32 radiometry",
             "data": "synthetic (scene.rs CornellBox constants, seeded BVH, device-generated rays)",
-            "config": {"workload": f"{args.scene} {w}x{h} {spp}spp depth {depth} (BASELINE.json configs[1])",
+            "config": {"workload": f"{args.scene} {w}x{h} {spp}spp depth {depth}" + (" (BASELINE.json configs[1])" if headline else ""),
                        "parallelism": f"spp-sharded x{world}" if world > 1 else "single GPU",
                        "rays_per_frame": rays_total // args.steps},
             "roofline": {
