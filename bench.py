@@ -263,7 +263,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64 geometry / f32 radiometry",
-            "data": "synthetic (scene.rs CornellBox constants, seeded BVH, device-generated rays)",
+            "data": f"synthetic (scene.rs {args.scene} constants, seeded BVH, device-generated rays)",
             "config": {"workload": f"{args.scene} {w}x{h} {spp}spp depth {depth}" + (" (BASELINE.json configs[1])" if headline else ""),
                        "parallelism": f"spp-sharded x{world}" if world > 1 else "single GPU",
                        "rays_per_frame": rays_total // args.steps},
