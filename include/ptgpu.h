@@ -31,7 +31,8 @@ typedef enum PtStatus {
     PT_ERR_OOM = -3,         /* device allocation failed */
     PT_ERR_NO_SCENE = -4,    /* render / trace before pt_scene_upload */
     PT_ERR_NO_DEVICE = -5,   /* no usable GPU */
-    PT_ERR_STATE = -6        /* call out of order (e.g. resolve before pt_accum_reset) */
+    PT_ERR_STATE = -6,       /* call out of order (e.g. resolve before pt_accum_reset) */
+    PT_ERR_RCCL = -7         /* librccl could not be loaded, or an RCCL call failed (message carries ncclGetErrorString) */
 } PtStatus;
 
 /* ---- primitives: geometry.rs Sphere (:104-171), RectangleXY/XZ/YZ (:182-369), Triangle (:466-589).
@@ -117,7 +118,10 @@ typedef struct PtHitOut {
     double normal[3];    /* flipped to oppose the ray, geometry.rs:33-37 */
 } PtHitOut;
 
-/* Per-call statistics of pt_render_accumulate.  Kernel times are HIP-event times on the context's stream. */
+/* Per-call statistics of pt_render_accumulate.  Kernel times are HIP-event times on the stream each kernel is launched on.
+ * ms_<kernel> is the SUM of that kernel's launch durations; with several lanes (sub-passes on separate streams) launches
+ * of one kernel overlap each other and the other kernels, so the sums can exceed ms_total.  ms_busy_<kernel> is the length
+ * of the UNION of the same intervals: the time during which at least one launch of that kernel was running. */
 typedef struct PtStats {
     uint64_t rays;            /* hit queries issued (= Ray::color calls with bounces_left > 0, ray.rs:25) */
     uint64_t paths;           /* primary samples started */
@@ -132,6 +136,10 @@ typedef struct PtStats {
     double ms_fold;
     double ms_repack;
     double ms_path;           /* the fused path kernel / the tail kernel (trace + shade of several bounces in one launch) */
+    double ms_busy_trace;     /* union of the trace launches' intervals */
+    double ms_busy_shade;
+    double ms_busy_path;
+    double ms_busy_all;       /* union over every kernel of the call (<= ms_total; the rest is launch gaps) */
     uint64_t rays_per_bounce[64]; /* live rays entering bounce b (b >= 64 folded into the last slot) */
 } PtStats;
 
@@ -203,6 +211,19 @@ int pt_accum_upload(PtContext* ctx, const float* rgb_sum);
 
 /* Device address of the current accumulation buffer (internal or bound); NULL before pt_accum_reset. */
 void* pt_accum_device_ptr(PtContext* ctx);
+
+/* The exchange step of a sample-sharded frame (the loop being sharded is renderer.rs:19-28): sums the
+ * accumulation buffers of n contexts -- one per GPU, all of one size, each after its own pt_render_accumulate calls
+ * on its own sample range -- into ctxs[0]'s buffer with ONE RCCL ncclReduce(f32, sum, root 0) over xGMI
+ * (width*height*3 floats: 24.9 MB at 1080p, 99.5 MB at 4K), each rank's part enqueued on that context's stream
+ * inside one ncclGroupStart/End.  The other contexts' buffers are left as they were.  Returns after every stream has
+ * drained; ctxs[0] can then be resolved with the TOTAL spp.  n == 1 is the identity (and still goes through RCCL).
+ * The communicators (ncclCommInitAll over the contexts' devices, in the order given) are created on first use and
+ * kept for the process.  librccl.so.1 is loaded on the first call, not at link time: a host that never shards needs no
+ * RCCL.  One thread calls this for all n contexts, after the threads that drove them have returned from their calls.
+ * PT_ERR_BAD_ARG: null / repeated context, two contexts on one device, sizes differ; PT_ERR_STATE: before
+ * pt_accum_reset; PT_ERR_RCCL: library missing or an RCCL call failed. */
+int pt_accum_reduce(PtContext** ctxs, int n);
 
 /* Device-side checks of the arithmetic the parity contract leans on (IEEE division and sqrt, the Philox
  * stream): computes a[i]/b[i] and sqrt(|a[i]|) on the GPU for host arrays of n doubles. */

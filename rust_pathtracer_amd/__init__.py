@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     PtTexture,
     PtError,
     Scene,
+    accum_reduce,
     camera_new,
     write_png,
     selftest_guide_tree,

@@ -118,6 +118,10 @@ class PtStats(C.Structure):
         ("ms_fold", C.c_double),
         ("ms_repack", C.c_double),
         ("ms_path", C.c_double),
+        ("ms_busy_trace", C.c_double),
+        ("ms_busy_shade", C.c_double),
+        ("ms_busy_path", C.c_double),
+        ("ms_busy_all", C.c_double),
         ("rays_per_bounce", C.c_uint64 * 64),
     ]
 
@@ -177,6 +181,7 @@ _PTGPU_PROTOS = {
     "pt_accum_download": (C.c_int, [_vp, _vp]),
     "pt_accum_upload": (C.c_int, [_vp, _vp]),
     "pt_accum_device_ptr": (_vp, [_vp]),
+    "pt_accum_reduce": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "pt_selftest_arith": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "pt_selftest_division": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "pt_selftest_rng": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
@@ -241,6 +246,14 @@ def device_count() -> int:
     if n < 0:
         raise PtError(libptgpu.pt_last_error(None).decode())
     return n
+
+
+def accum_reduce(contexts) -> None:
+    """pt_accum_reduce: sums the accumulation buffers of `contexts` (one per GPU) into contexts[0]'s with one RCCL reduce."""
+    arr = (_vp * len(contexts))(*[c._h for c in contexts])
+    rc = libptgpu.pt_accum_reduce(arr, len(contexts))
+    if rc != 0:
+        raise PtError(f"pt_accum_reduce: status {rc}: {libptgpu.pt_last_error(contexts[0]._h if contexts else None).decode()}")
 
 
 def selftest_guide_tree(boxes: np.ndarray):

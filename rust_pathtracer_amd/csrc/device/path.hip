@@ -208,7 +208,7 @@ void launch_tail(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const P
     a.max_bounces = p.max_bounces;
     a.first_buf = io.in;
     a.env = make_shade_env(p, wf, first_bounce);
-    a.os = OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes};
+    a.os = ordered_scene(sc);
     const bool lds = sc.n_prims <= PT_SHADE_LDS_MAX_PRIMS;
     // one instance per (texture kinds present, ShadePrim table in LDS or not)
     auto launch = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, sc, a); };

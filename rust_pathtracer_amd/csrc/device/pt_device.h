@@ -48,11 +48,8 @@ __device__ __forceinline__ bool near_zero(V3 a) {                               
 // thread_rng (renderer.rs:23-24, vec3.rs:27-29,35-37,59-60, material.rs:132).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                               uint32_t out[4]) {
-#ifndef PT_PHILOX_ROUNDS
-#define PT_PHILOX_ROUNDS 10
-#endif
 #pragma unroll
-    for (int r = 0; r < PT_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < 10; ++r) {
         // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of separate low and high multiplies
         uint64_t p0 = (uint64_t)c0 * 0xD2511F53ull, p1 = (uint64_t)c2 * 0xCD9E8D57ull;
         uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -98,9 +95,6 @@ __device__ __forceinline__ V3 random_in_unitsphere(SampleRng& rng) { // vec3.rs:
         double y = rng.range(-1.0, 1.0);
         double z = rng.range(-1.0, 1.0);
         p = v3(x, y, z);
-#ifdef PT_ABLATE_NO_REJECT
-        break;
-#endif
         if (len_squared(p) < 1.0) break;
     }
     return p;
@@ -274,6 +268,10 @@ struct DevScene {
     const ShadePrim* shade_prims;
     const unsigned char* guide; // the guide tree of the ordered walk (guide_tree.h), node 0 = root; null when there is none
     uint32_t guide_nodes;
+    // which rays the ordered walk may take (computed at upload from the primitives' sizes, see pt_scene_upload):
+    double ow_origin_limit; // |o|inf at most this ...
+    double ow_tri_extent;   // ... and (|o|inf + ow_tri_extent) * |d|inf at most ow_od_limit
+    double ow_od_limit;
 };
 
 // ------------------------------------------------------------------ hit tests (t only; the record is rebuilt in shade)
@@ -552,11 +550,7 @@ __device__ __forceinline__ void walk_rect(LaneMask act, double k, double a_lo, d
                                           double dn, double inv_dn, double oa, double da, double ob, double db, double t_min,
                                           uint32_t prim, double& best_t, int32_t& best_prim) {
     const double n = k - on;
-#ifdef PT_NO_FAST_DIV
-    const double t = n / dn;
-#else
     const double t = PROVEN ? div_proven(n, dn, inv_dn) : div_ieee_unspeculated(n, dn);
-#endif
     const double a = oa + t * da;
     const double b = ob + t * db;
     asm volatile(
@@ -818,7 +812,11 @@ struct OrderedScene { // wave-uniform: what the ordered walk reads
     const unsigned char* guide;  // guide tree: guide_nodes records of 64 bytes, node 0 = root
     const unsigned char* stream; // record stream with parent links, padded by 128 bytes
     uint32_t guide_nodes, stream_bytes;
+    double origin_limit, tri_extent, od_limit; // DevScene::ow_*
 };
+__host__ __device__ inline OrderedScene ordered_scene(const DevScene& sc) {
+    return OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes, sc.ow_origin_limit, sc.ow_tri_extent, sc.ow_od_limit};
+}
 struct OrderedWalk {
     StreamWalk w;     // the ray, t_min, the best hit so far, and the fetched 56 bytes (kind, aux, g[6])
     uint2 tail;       // bytes 56..63 of the fetch (triangle: the 7th double)
@@ -898,10 +896,16 @@ struct OrderedWalk {
         // a NaN, which is what the guide's arithmetic, the nesting argument AND the premise "a primitive that reports a
         // hit is crossed inside its box" rest on: the reference accepts a sphere whose discriminant is inf - inf = NaN
         // (geometry.rs:132-148: every comparison with NaN is false) wherever the ray is, and a NaN bound then lets any
-        // later hit replace a nearer one.  Such rays take the literal walk.
+        // later hit replace a nearer one.  The same premise fails without any NaN when the origin is far from a
+        // primitive relative to the primitive's size: the tests cancel and report hits for rays that pass whole units
+        // beside it (a sphere of radius 0.5 seen from 1e9 away), outside the 1e-5 padding of its guide box, where the
+        // reference -- which tests it whenever its parent's box is crossed -- still takes the hit.  The upload turns the
+        // sizes of the scene's primitives into the two limits below (origin_limit <= 2^100).  All other rays take the
+        // literal walk.
+        const double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
         const bool ordinary = fabs(w.inv.x) <= 0x1p100 && fabs(w.inv.y) <= 0x1p100 && fabs(w.inv.z) <= 0x1p100 && fabs(w.inv.x) >= 0x1p-100 &&
-                              fabs(w.inv.y) >= 0x1p-100 && fabs(w.inv.z) >= 0x1p-100 && fabs(o.x) <= 0x1p100 && fabs(o.y) <= 0x1p100 &&
-                              fabs(o.z) <= 0x1p100 && t_min == t_min && t_max_ == t_max_;
+                              fabs(w.inv.y) >= 0x1p-100 && fabs(w.inv.z) >= 0x1p-100 && omax <= sc.origin_limit &&
+                              (omax + sc.tri_extent) * dmax <= sc.od_limit && t_min == t_min && t_max_ == t_max_;
         advance(sc, nullptr, ordinary, 0u, !ordinary);
     }
     // one child's box against the ray: entry and exit parameters, each moved outwards by 1e-9 of itself

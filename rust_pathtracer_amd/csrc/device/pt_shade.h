@@ -135,13 +135,7 @@ __device__ __forceinline__ void shade_chunk(const DevScene& sc, const ShadeEnv& 
     if (env.last_bounce) return; // nothing survives the last bounce
     // ---- the wave: unit-sphere points for the lanes that asked (vec3.rs:41-49), then their scattered directions
     if (wave_any(need_point)) {
-#ifdef PT_ABLATE_NO_SAMPLER
-        const V3 point = v3(0.3 + 1e-9 * pixel, 0.4, 0.5 - 1e-9 * sample);
-#elif defined(PT_ABLATE_ONE_ROUND)
-        V3 point; bool acc_; unitsphere_pair(pixel, sample, env.stream, 0u, env.k0, env.k1, point, acc_);
-#else
         const V3 point = random_in_unitsphere_wave(need_point, pixel, sample, env.stream, env.k0, env.k1, exchange);
-#endif
         if (need_point) next_d = scatter_finish(mat_type, mat_param, base, point);
     }
 }

@@ -1,10 +1,16 @@
 // ptgpu.hip -- implementation of the C ABI in include/ptgpu.h: context, scene upload, the wavefront driver.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
+
+#include <rccl/rccl.h> // types and prototypes only: the library is loaded on the first pt_accum_reduce (dlopen)
 
 #include "guide_tree.h"
 #include "pt_launch.h"
@@ -505,6 +511,16 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     const bool large = (uint64_t)s->n_nodes + s->n_prims > PT_WALK_MAX_ITEMS;
     const bool want_guide = ctx->trace_mode_override == PT_TRACE_ORDERED || (ctx->trace_mode_override < 0 && large);
     bool boxes_nested = true;
+    // Which rays the ordered walk may take (pt_device.h OrderedWalk::begin).  Its argument needs "a primitive test that
+    // reports a hit is crossed inside its padded guide box" for EVERY primitive of the scene, tested or not; a ray whose
+    // origin is far from a primitive relative to the primitive's size loses that to cancellation (a sphere's discriminant,
+    // a triangle's barycentrics) while the padding is only 1e-5 of the leaf's largest coordinate m.  Per kind, with the
+    // rounding of the tests bounded generously (constants leave a factor of 2 or more):
+    //   sphere    false-hit distance ~ 4e-16 |o - c|^2 / (2|r|) <= 1e-5 |r|  if  |o|inf <= 5e4 |r| - |c|inf
+    //   rectangle in-plane error ~ 2^-51 (|o| + extent) <= 1e-5 m             if  |o|inf <= 2e10 m - extent
+    //   triangle  barycentric error <= 1e-15 |o - p1| |d| |e| / det with det >= 1e-4 (geometry.rs:526), times the other edge:
+    //             <= 1e-5 m  if  (|o|inf + extent of the triangles) |d|inf <= 8e4 / max(|e1| |e2| / m)
+    double ow_origin_limit = 0x1p100, ow_tri_ratio = 0.0, ow_tri_extent = 0.0, ow_rect_m = INFINITY, ow_rect_extent = 0.0;
     {
         auto leaf_box = [&](const double* lo, const double* hi) {
             GuideLeaf l;
@@ -512,6 +528,9 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
             l.offset = (uint32_t)std::min<size_t>(walk.size() * 8u, 0xFFFFFFFFu);
             guide::pad(l);
             guide_leaves.push_back(l);
+            double m = 0.0;
+            for (int q = 0; q < 3; ++q) m = std::max(m, std::max(std::fabs(lo[q]), std::fabs(hi[q])));
+            return m; // the leaf's largest coordinate: what its padding is proportional to
         };
         // (parent_word: for primitive records of a stream built for the ordered walk, where the parent node's record starts)
         auto put_header = [&](uint32_t kind, uint32_t aux_word, uint32_t parent_word = 0) {
@@ -548,7 +567,9 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
                     }
                     if (as_box) {
                         const double lo[3] = {x0, y0, z0}, hi[3] = {x1, y1, z1};
-                        leaf_box(lo, hi);
+                        const double m = leaf_box(lo, hi);
+                        ow_rect_m = std::min(ow_rect_m, m);
+                        ow_rect_extent = std::max(ow_rect_extent, m);
                         put_header(PT_WK_BOX6, first, parent);
                         for (double v : {x0, y0, z0, x1, y1, z1}) {
                             put(v);
@@ -575,7 +596,19 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
                             lo[aa] = pr.d[1]; hi[aa] = pr.d[2];
                             lo[ba] = pr.d[3]; hi[ba] = pr.d[4];
                         }
-                        leaf_box(lo, hi);
+                        const double m = leaf_box(lo, hi);
+                        if (pr.type == PT_PRIM_SPHERE) {
+                            const double c = std::max(std::fabs(pr.d[0]), std::max(std::fabs(pr.d[1]), std::fabs(pr.d[2])));
+                            ow_origin_limit = std::min(ow_origin_limit, 5e4 * std::fabs(pr.d[3]) - c);
+                        } else if (pr.type == PT_PRIM_TRIANGLE) {
+                            const double e1 = std::sqrt(pr.d[3] * pr.d[3] + pr.d[4] * pr.d[4] + pr.d[5] * pr.d[5]);
+                            const double e2 = std::sqrt(pr.d[6] * pr.d[6] + pr.d[7] * pr.d[7] + pr.d[8] * pr.d[8]);
+                            ow_tri_ratio = std::max(ow_tri_ratio, m > 0.0 ? e1 * e2 / m : INFINITY);
+                            ow_tri_extent = std::max(ow_tri_extent, m);
+                        } else {
+                            ow_rect_m = std::min(ow_rect_m, m);
+                            ow_rect_extent = std::max(ow_rect_extent, m);
+                        }
                     }
                     if (pr.type == PT_PRIM_SPHERE) {
                         put_header(PT_WK_SPHERE, first + k, parent);
@@ -678,6 +711,10 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     if (ctx->trace_mode_override >= 0) sc.trace_mode = (uint32_t)ctx->trace_mode_override;
     if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds
     sc.walk_flags = walk_flags;
+    if (std::isfinite(ow_rect_m)) ow_origin_limit = std::min(ow_origin_limit, 2e10 * ow_rect_m - ow_rect_extent);
+    sc.ow_origin_limit = ow_origin_limit == ow_origin_limit ? ow_origin_limit : -1.0; // (negative or NaN: no ray qualifies)
+    sc.ow_tri_extent = ow_tri_extent;
+    sc.ow_od_limit = ow_tri_ratio > 0.0 ? 8e4 / ow_tri_ratio : __builtin_huge_val();
     sc.shade_prims = (const ShadePrim*)ctx->d_shade.p;
     sc.has_procedural = PT_PROC_NONE;
     for (uint32_t i = 0; i < s->n_textures; ++i) {
@@ -893,14 +930,19 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         pl.steps.push_back({K_TOTALS, 0, BounceIO{0, 1, nullptr, nullptr}});
     };
 
+    size_t ev_begin = 0, ev_end = 0;
+    uint32_t passes = 0, launches_trace = 0, launches_shade = 0, launches_path = 0;
+    std::vector<unsigned long long> totals((size_t)n_counts * PT_MAX_LANES, 0);
+    const bool profile = ctx->profile != 0;
+    // Everything that enqueues work.  A failure in here returns with kernels possibly still running on the other lanes'
+    // streams: the caller below drains every lane before the error leaves the library.
+    auto enqueue = [&]() -> int {
     for (int l = 0; l < n_lanes; ++l)
         PT_HIP(ctx, hipMemsetAsync(ctx->lanes[l].wf.totals, 0, (size_t)n_counts * sizeof(unsigned long long), ctx->lanes[l].stream));
-    size_t ev_begin = 0, ev_end = 0;
     PT_HIP(ctx, new_event(ev_begin));
     PT_HIP(ctx, hipEventRecord(ctx->events[ev_begin], ctx->stream));
     for (int l = 1; l < n_lanes; ++l) PT_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->events[ev_begin], 0));
 
-    uint32_t passes = 0, launches_trace = 0, launches_shade = 0, launches_path = 0;
     long fold_guard = -1;  // stop event of the last fold: folds add to the same buffer and must not overlap
     for (uint32_t done = 0; done < sample_count; done += slots) {
         const uint32_t cur = std::min(slots, sample_count - done);
@@ -932,10 +974,15 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                         PT_HIP(ctx, hipStreamWaitEvent(ln.stream, ctx->events[(size_t)plan[prev].last_stop], 0));
                 }
                 if (st.kind == K_FOLD && fold_guard >= 0) PT_HIP(ctx, hipStreamWaitEvent(ln.stream, ctx->events[(size_t)fold_guard], 0));
+                // Without profiling only the hand-offs are recorded: a raygen's end (the next lane's start waits for it) and
+                // a fold's (folds add to one buffer and must not overlap); with lane_sync every step is a hand-off.
+                const bool want_stop = profile || ctx->lane_sync || st.kind == K_RAYGEN || st.kind == K_FOLD;
                 Timed t{st.kind, 0, 0};
-                PT_HIP(ctx, new_event(t.start));
-                PT_HIP(ctx, new_event(t.stop));
-                PT_HIP(ctx, hipEventRecord(ctx->events[t.start], ln.stream));
+                if (profile) {
+                    PT_HIP(ctx, new_event(t.start));
+                    PT_HIP(ctx, hipEventRecord(ctx->events[t.start], ln.stream));
+                }
+                if (want_stop) PT_HIP(ctx, new_event(t.stop));
                 switch (st.kind) {
                     case K_RAYGEN: launch_raygen(ln.stream, geom, *camera, plan[l].p, ln.wf); break;
                     case K_PATH: launch_path(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_path; break;
@@ -946,10 +993,12 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_FOLD: launch_fold(ln.stream, plan[l].p, ln.wf, plan[l].slots, ctx->d_accum); break;
                     default: launch_count_totals(ln.stream, ln.wf, max_bounces); break;
                 }
-                PT_HIP(ctx, hipEventRecord(ctx->events[t.stop], ln.stream));
-                if (st.kind == K_FOLD) fold_guard = (long)t.stop;
-                stop_of[l] = (long)t.stop;
-                timed.push_back(t);
+                if (want_stop) {
+                    PT_HIP(ctx, hipEventRecord(ctx->events[t.stop], ln.stream));
+                    if (st.kind == K_FOLD) fold_guard = (long)t.stop;
+                    stop_of[l] = (long)t.stop;
+                }
+                if (profile) timed.push_back(t);
             }
             for (int l = 0; l < active; ++l) plan[l].last_stop = stop_of[l];
         }
@@ -965,12 +1014,21 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
     }
     PT_HIP(ctx, new_event(ev_end));
     PT_HIP(ctx, hipEventRecord(ctx->events[ev_end], ctx->stream));
-    std::vector<unsigned long long> totals((size_t)n_counts * PT_MAX_LANES, 0);
     for (int l = 0; l < n_lanes; ++l)
         PT_HIP(ctx, hipMemcpyAsync(totals.data() + (size_t)l * n_counts, ctx->lanes[l].wf.totals,
                                    (size_t)n_counts * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int l = 1; l < n_lanes; ++l) PT_HIP(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
+    return PT_OK;
+    };
+    const int enqueue_rc = enqueue();
+    // drain every lane, whatever happened above (ptgpu.h: calls return after the context's streams have drained)
+    hipError_t drain_err = hipSuccess;
+    for (int l = 0; l < PT_MAX_LANES; ++l) {
+        if (!ctx->lanes[l].stream) continue;
+        hipError_t e = hipStreamSynchronize(ctx->lanes[l].stream);
+        if (e != hipSuccess && drain_err == hipSuccess) drain_err = e;
+    }
+    if (enqueue_rc != PT_OK) return enqueue_rc; // (its message stands)
+    if (drain_err != hipSuccess) return ctx->fail_hip("pt_render_accumulate: hipStreamSynchronize", drain_err);
 
     if (stats) {
         stats->paths = (uint64_t)npix * sample_count;
@@ -984,22 +1042,58 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
             stats->rays += v;
             stats->rays_per_bounce[std::min<uint32_t>(b, 63)] += v;
         }
-        if (ctx->profile) {
-            float ms = 0.f;
-            PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[ev_begin], ctx->events[ev_end]));
-            stats->ms_total = ms;
+        // Timing is a by-product: an event that cannot be read zeroes the times, it does not fail a finished render.
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->events[ev_begin], ctx->events[ev_end]) == hipSuccess) stats->ms_total = ms;
+        else (void)hipGetLastError();
+        if (profile) {
+            bool ok = true;
+            std::vector<std::pair<float, float>> spans[3], all; // [trace, shade, path] launch intervals since ev_begin
+            all.reserve(timed.size());
             for (const Timed& t : timed) {
-                PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->events[t.start], ctx->events[t.stop]));
+                float t0 = 0.f, t1 = 0.f;
+                if (hipEventElapsedTime(&t0, ctx->events[ev_begin], ctx->events[t.start]) != hipSuccess ||
+                    hipEventElapsedTime(&t1, ctx->events[ev_begin], ctx->events[t.stop]) != hipSuccess) {
+                    ok = false;
+                    break;
+                }
+                ms = t1 - t0;
                 switch (t.kind) {
                     case K_RAYGEN: stats->ms_raygen += ms; break;
-                    case K_TRACE: stats->ms_trace += ms; break;
-                    case K_SHADE: stats->ms_shade += ms; break;
+                    case K_TRACE: stats->ms_trace += ms; spans[0].emplace_back(t0, t1); break;
+                    case K_SHADE: stats->ms_shade += ms; spans[1].emplace_back(t0, t1); break;
                     case K_FOLD: stats->ms_fold += ms; break;
                     case K_REPACK: stats->ms_repack += ms; break;
-                    case K_PATH: stats->ms_path += ms; break;
-                    case K_TAIL: stats->ms_path += ms; break;
+                    case K_PATH: stats->ms_path += ms; spans[2].emplace_back(t0, t1); break;
+                    case K_TAIL: stats->ms_path += ms; spans[2].emplace_back(t0, t1); break;
                     default: break;
                 }
+                if (t.kind != K_TOTALS) all.emplace_back(t0, t1);
+            }
+            auto union_ms = [](std::vector<std::pair<float, float>>& v) {
+                std::sort(v.begin(), v.end());
+                double sum = 0.0;
+                float lo = 0.f, hi = -1.f;
+                for (const auto& iv : v) {
+                    if (hi < lo || iv.first > hi) {
+                        if (hi >= lo) sum += (double)hi - lo;
+                        lo = iv.first;
+                        hi = iv.second;
+                    } else {
+                        hi = std::max(hi, iv.second);
+                    }
+                }
+                if (hi >= lo) sum += (double)hi - lo;
+                return sum;
+            };
+            if (ok) {
+                stats->ms_busy_trace = union_ms(spans[0]);
+                stats->ms_busy_shade = union_ms(spans[1]);
+                stats->ms_busy_path = union_ms(spans[2]);
+                stats->ms_busy_all = union_ms(all);
+            } else {
+                (void)hipGetLastError();
+                stats->ms_raygen = stats->ms_trace = stats->ms_shade = stats->ms_fold = stats->ms_repack = stats->ms_path = 0.0;
             }
         }
     }
@@ -1040,6 +1134,124 @@ int pt_accum_upload(PtContext* ctx, const float* rgb_sum) {
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PT_OK;
 }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ the multi-GPU exchange
+namespace {
+// librccl.so.1, resolved on first use: a host that never shards carries no RCCL dependency (the static archive links without it).
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error; // why loading failed
+    bool load() {
+        if (lib) return true;
+        if (!error.empty()) return false;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) {
+            const char* why = dlerror();
+            error = std::string("cannot load librccl.so.1: ") + (why ? why : "unknown error");
+            return false;
+        }
+        auto sym = [&](const char* n) {
+            void* f = dlsym(lib, n);
+            if (!f && error.empty()) error = std::string("librccl lacks ") + n;
+            return f;
+        };
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(sym("ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+        Reduce = reinterpret_cast<decltype(Reduce)>(sym("ncclReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+        if (!error.empty()) {
+            dlclose(lib);
+            lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+std::mutex g_rccl_mutex;                                   // one reduce at a time per process
+Rccl g_rccl;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms; // device list (rank order) -> its clique, kept for the process
+}  // namespace
+
+extern "C" int pt_accum_reduce(PtContext** ctxs, int n) {
+    if (!ctxs || n < 1) {
+        g_last_error = "pt_accum_reduce: no contexts";
+        return PT_ERR_BAD_ARG;
+    }
+    PtContext* root = ctxs[0];
+    if (!root) {
+        g_last_error = "pt_accum_reduce: null context";
+        return PT_ERR_BAD_ARG;
+    }
+    auto fail_all = [&](int code, const std::string& msg) { // the message is readable from every context of the call
+        for (int i = 0; i < n; ++i)
+            if (ctxs[i]) ctxs[i]->err = msg;
+        g_last_error = msg;
+        return code;
+    };
+    std::vector<int> devices((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return fail_all(PT_ERR_BAD_ARG, "pt_accum_reduce: null context");
+        if (ctxs[i]->width == 0 || !ctxs[i]->d_accum) return fail_all(PT_ERR_STATE, "pt_accum_reduce before pt_accum_reset");
+        if (ctxs[i]->width != root->width || ctxs[i]->height != root->height)
+            return fail_all(PT_ERR_BAD_ARG, "pt_accum_reduce: accumulation buffers differ in size");
+        devices[(size_t)i] = ctxs[i]->device;
+        for (int k = 0; k < i; ++k)
+            if (ctxs[k] == ctxs[i] || ctxs[k]->device == ctxs[i]->device)
+                return fail_all(PT_ERR_BAD_ARG, "pt_accum_reduce: one context per GPU (a context or a device is listed twice)");
+    }
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    Rccl& r = g_rccl;
+    if (!r.load()) return fail_all(PT_ERR_RCCL, "pt_accum_reduce: " + r.error);
+    auto rccl_fail = [&](const char* what, ncclResult_t e) { return fail_all(PT_ERR_RCCL, std::string(what) + ": " + r.GetErrorString(e)); };
+    auto hip_fail = [&](const char* what, hipError_t e) { return fail_all(PT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+
+    auto it = g_comms.find(devices);
+    if (it == g_comms.end()) {
+        std::vector<ncclComm_t> comms((size_t)n, nullptr);
+        ncclResult_t e = r.CommInitAll(comms.data(), n, devices.data());
+        if (e != ncclSuccess) return rccl_fail("ncclCommInitAll", e);
+        it = g_comms.emplace(devices, std::move(comms)).first;
+    }
+    const std::vector<ncclComm_t>& comms = it->second;
+    const size_t count = (size_t)root->width * root->height * 3;
+    // every context's earlier work (its render) runs on its own stream: the reduce is ordered behind it there
+    ncclResult_t e = r.GroupStart();
+    if (e != ncclSuccess) return rccl_fail("ncclGroupStart", e);
+    ncclResult_t first_bad = ncclSuccess;
+    for (int i = 0; i < n; ++i) {
+        hipError_t he = hipSetDevice(ctxs[i]->device);
+        if (he != hipSuccess) {
+            (void)r.GroupEnd();
+            return hip_fail("hipSetDevice", he);
+        }
+        e = r.Reduce(ctxs[i]->d_accum, ctxs[i]->d_accum, count, ncclFloat32, ncclSum, 0, comms[(size_t)i], ctxs[i]->stream);
+        if (e != ncclSuccess && first_bad == ncclSuccess) first_bad = e;
+    }
+    e = r.GroupEnd();
+    if (first_bad != ncclSuccess) return rccl_fail("ncclReduce", first_bad);
+    if (e != ncclSuccess) return rccl_fail("ncclGroupEnd", e);
+    for (int i = 0; i < n; ++i) {
+        hipError_t he = hipSetDevice(ctxs[i]->device);
+        if (he == hipSuccess) he = hipStreamSynchronize(ctxs[i]->stream);
+        if (he != hipSuccess) return hip_fail("pt_accum_reduce: hipStreamSynchronize", he);
+    }
+    return PT_OK;
+}
+
+extern "C" {
 
 static int selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root, int via_reciprocal) {
     if (!ctx) return PT_ERR_BAD_ARG;

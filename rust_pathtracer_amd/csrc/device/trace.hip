@@ -148,7 +148,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_ORD
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io) {
     const RayStream& in = wf.rays[io.in];
     if (sc.trace_mode == PT_TRACE_ORDERED) {
-        hipLaunchKernelGGL(trace_ordered_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes}, in,
+        hipLaunchKernelGGL(trace_ordered_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, ordered_scene(sc), in,
                            io.counts_in, wf.n_waves, wf.hit_t, wf.hit_prim);
         return;
     }
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_batch_ordered_kernel(DevScene 
                                                                        const double* __restrict__ dirs, uint32_t n, double t_min,
                                                                        double t_max, PtHitOut* __restrict__ out) {
     __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
-    const OrderedScene os{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes};
+    const OrderedScene os = ordered_scene(sc);
     const uint32_t waves = gridDim.x * (blockDim.x / PT_WAVE), wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t per_wave = (n + waves - 1u) / waves; // rays [wave * per_wave, ...) belong to this wave
     const uint64_t first = (uint64_t)wave * per_wave;

@@ -330,12 +330,20 @@ int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_di
         if (frames_total) *frames_total = (uint32_t)amount_of_frames;
         s->seconds_build = s->seconds_upload = 0.0;
         if (s->rebuild_per_frame && !s->scene) throw std::runtime_error("pth_render_frames: a world made by pth_world_create cannot be rebuilt");
-        std::thread writer;
-        std::string write_error;
         double t_render = 0.0, t_write = 0.0;
         uint32_t written = 0;
         uint64_t ray_sum = 0;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        std::string write_error;
+        std::thread writer;
+        // Joined on EVERY way out of this scope: an exception from the next frame's render or upload must not unwind past a
+        // joinable std::thread (that is std::terminate, and the host process with it).
+        struct Joiner {
+            std::thread& t;
+            ~Joiner() {
+                if (t.joinable()) t.join();
+            }
+        } joiner{writer};
         for (uint64_t frame_index = first_frame; frame_index < amount_of_frames && written < (max_frames ? max_frames : 0xFFFFFFFFu);
              frame_index += frame_stride) {
             const double t = (double)frame_index / (double)amount_of_frames;  // main.rs:52

@@ -1,6 +1,7 @@
 // renderer.cpp -- see renderer.hpp.
 #include "renderer.hpp"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace pt {
@@ -40,24 +41,36 @@ std::vector<uint8_t> GpuRenderer::render(const Camera& camera, size_t width, siz
 
 namespace {
 std::mutex g_mutex;
-std::unique_ptr<GpuRenderer> g_renderer;
-const BvhNode* g_world = nullptr;
+GpuRenderer* g_renderer = nullptr; // released by render_shutdown(), registered with atexit AFTER the HIP runtime initialised:
+                                   // it then runs before the runtime's own teardown (a static destructor might not)
+uint64_t g_generation = 0;         // BvhNode::generation of the uploaded world; 0 = none
 } // namespace
+
+void render_shutdown() {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    delete g_renderer;
+    g_renderer = nullptr;
+    g_generation = 0;
+}
 
 std::vector<uint8_t> render(const BvhNode& world, const Camera& camera, size_t width, size_t height, const Color& background,
                             size_t samples_per_pixel, size_t max_bounces, uint64_t seed, PtStats* stats) {
     std::lock_guard<std::mutex> lock(g_mutex);
-    if (!g_renderer) g_renderer.reset(new GpuRenderer(0));
-    if (g_world != &world) {
+    if (!g_renderer) {
+        g_renderer = new GpuRenderer(0); // (pt_context_create has touched the device: HIP is up)
+        std::atexit([] { render_shutdown(); });
+    }
+    if (g_generation != world.generation) {
+        g_generation = 0;
         g_renderer->upload(world);
-        g_world = &world;
+        g_generation = world.generation;
     }
     return g_renderer->render(camera, width, height, background, samples_per_pixel, max_bounces, seed, stats);
 }
 
 void render_invalidate_cache() {
     std::lock_guard<std::mutex> lock(g_mutex);
-    g_world = nullptr;
+    g_generation = 0;
 }
 
 } // namespace pt

@@ -28,9 +28,12 @@ private:
 
 // Drop-in for renderer::render: uploads `world` to the process-wide renderer on device 0 when it is not the
 // world rendered last (the reference renders many frames from one world, main.rs:23,51-64), then renders.
+// "The world rendered last" is decided by BvhNode::generation (assigned at construction), not by address.
 std::vector<uint8_t> render(const BvhNode& world, const Camera& camera, size_t width, size_t height, const Color& background,
                             size_t samples_per_pixel, size_t max_bounces, uint64_t seed = 0, PtStats* stats = nullptr);
-// Forget the cached world of the process-wide renderer (call after mutating or freeing a world).
+// Forget the cached world of the process-wide renderer (call after mutating a world's nodes in place).
 void render_invalidate_cache();
+// Destroys the process-wide renderer and its GPU context (also registered with atexit by its first use).
+void render_shutdown();
 
 } // namespace pt

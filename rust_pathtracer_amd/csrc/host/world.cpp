@@ -1,6 +1,8 @@
 // world.cpp -- BvhNode::new and the flatten() bodies of world.hpp.
 #include "world.hpp"
 
+#include <atomic>
+
 #include <numeric>
 
 namespace pt {
@@ -129,6 +131,11 @@ uint32_t BvhNode::flatten(Flattener& f) const {
     n.left = l;
     n.right = r;
     return idx;
+}
+
+uint64_t BvhNode::next_generation() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
 }
 
 } // namespace pt

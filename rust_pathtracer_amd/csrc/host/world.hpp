@@ -235,6 +235,10 @@ struct Triangle : Hittable { // geometry.rs:466-589
 struct BvhNode : Hittable {
     HittablePtr left, right;
     Aabb bbox;
+    // Identifies this tree among all trees built by the process (a copy keeps it: same contents).  pt::render() keys its
+    // upload cache on it -- never on an address, which a later world can reuse.
+    uint64_t generation = next_generation();
+    static uint64_t next_generation();
     // BvhNode::new (bvh.rs:65-103) with the axis draws taken from `rng` (the reference: thread_rng).
     // Throws std::runtime_error("creating BVH node from empty object list") where the reference panics (:76).
     BvhNode(const std::vector<HittablePtr>& objects, BuildRng& rng);

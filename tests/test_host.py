@@ -233,6 +233,19 @@ def test_obj_reader(pt, tmp_path, oracle):
         pt.Scene("ModelTest").set_model_path(str(tmp_path / "nomtl.obj"))
 
 
+def test_accum_reduce_argument_checks_need_no_gpu(pt):
+    """pt_accum_reduce refuses an empty or null context list before it touches RCCL or a device."""
+    import ctypes as C
+
+    assert pt.libptgpu.pt_accum_reduce(None, 0) == -1  # PT_ERR_BAD_ARG
+    assert b"no contexts" in pt.libptgpu.pt_last_error(None)
+    arr = (C.c_void_p * 2)(None, None)
+    assert pt.libptgpu.pt_accum_reduce(arr, 2) == -1
+    assert b"null context" in pt.libptgpu.pt_last_error(None)
+    with pytest.raises(pt.PtError):
+        pt.accum_reduce([])
+
+
 def test_sharding_rules(pt):
     for total in (0, 1, 7, 256, 1024):
         for world in (1, 2, 3, 4, 8):
@@ -280,6 +293,11 @@ def test_png_writer_round_trip(pt, tmp_path):
         path = str(tmp_path / f"a_{w}x{h}.png")
         pt.write_png(path, img)
         assert np.array_equal(read_png(path), img)
+        # and an independent decoder (PIL): the container is a PNG any reader accepts, not just the one above
+        Image = pytest.importorskip("PIL.Image")
+        with Image.open(path) as im:
+            assert im.mode == "RGB" and im.size == (w, h)
+            assert np.array_equal(np.asarray(im), img)
     with pytest.raises(pt.PtError, match="could not create image file"):
         pt.write_png(str(tmp_path / "no_such_dir" / "a.png"), np.zeros((2, 2, 3), np.uint8))
 
