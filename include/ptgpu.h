@@ -225,6 +225,17 @@ void* pt_accum_device_ptr(PtContext* ctx);
  * pt_accum_reset; PT_ERR_RCCL: library missing or an RCCL call failed. */
 int pt_accum_reduce(PtContext** ctxs, int n);
 
+/* pt_trace_batch for callers that cannot allocate device memory (HIP-graph capture around the call site, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and
+ * bit-identical results, but the device copies of the rays and of the hit records live in a fixed scratch array inside
+ * the library (a file-scope __device__ array, PT_TRACE_STATIC_MAX_RAYS * 88 bytes = 5.5 MiB held per GPU for the life of
+ * the process) instead of buffers allocated and freed per call: the call makes no hipMalloc / hipFree and no other
+ * allocating call.  n > PT_TRACE_STATIC_MAX_RAYS is refused with PT_ERR_BAD_ARG.  All calls on one GPU share that GPU's
+ * array, whatever the context: calls that overlap in time on one GPU race; the call returns after its stream drained. */
+#define PT_TRACE_STATIC_MAX_RAYS 65536u
+int pt_trace_batch_static(PtContext* ctx, const double* origins, const double* dirs, size_t n, double t_min, double t_max,
+                          PtHitOut* out);
+
 /* Device-side checks of the arithmetic the parity contract leans on (IEEE division and sqrt, the Philox
  * stream): computes a[i]/b[i] and sqrt(|a[i]|) on the GPU for host arrays of n doubles. */
 int pt_selftest_arith(PtContext* ctx, const double* a, const double* b, size_t n, double* quot, double* root);

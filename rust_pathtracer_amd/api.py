@@ -170,6 +170,7 @@ _PTGPU_PROTOS = {
     "pt_context_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
     "pt_scene_upload": (C.c_int, [_vp, C.POINTER(PtSceneDesc)]),
     "pt_trace_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_double, C.c_double, _vp]),
+    "pt_trace_batch_static": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_double, C.c_double, _vp]),
     "pt_accum_reset": (C.c_int, [_vp, C.c_uint32, C.c_uint32]),
     "pt_accum_bind": (C.c_int, [_vp, _vp]),
     "pt_render_accumulate": (
@@ -447,6 +448,15 @@ class Context:
         assert o.shape == d.shape
         out = np.zeros(o.shape[0], dtype=HIT_DTYPE)
         self._ok(libptgpu.pt_trace_batch(self._h, o.ctypes.data, d.ctypes.data, o.shape[0], t_min, t_max, out.ctypes.data))
+        return out
+
+    def trace_batch_static(self, origins: np.ndarray, dirs: np.ndarray, t_min=0.001, t_max=float("inf")) -> np.ndarray:
+        """pt_trace_batch_static: the same query staged in the library's fixed scratch array (no device allocation)."""
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        assert o.shape == d.shape
+        out = np.zeros(o.shape[0], dtype=HIT_DTYPE)
+        self._ok(libptgpu.pt_trace_batch_static(self._h, o.ctypes.data, d.ctypes.data, o.shape[0], t_min, t_max, out.ctypes.data))
         return out
 
     def accum_reset(self, width: int, height: int):

@@ -26,6 +26,12 @@
 #define PT_TAIL_MIN_PRIMS 65536u
 #endif
 
+// Staging area of pt_trace_batch_static (ptgpu.h): the device copies of one batch's rays and hit records.  Every GPU the
+// library runs on holds its own copy of this array at its own address for the life of the process.  Host code never uses
+// the array's name as an address: scratch_for_device() asks the runtime for this device's address once and keeps it.
+#define PT_STATIC_BYTES_PER_RAY 88u /* origin 24 + direction 24 + PtHitOut 40 */
+static __device__ __align__(256) unsigned char scratch[(size_t)PT_TRACE_STATIC_MAX_RAYS * PT_STATIC_BYTES_PER_RAY];
+
 namespace {
 thread_local std::string g_last_error;
 
@@ -75,6 +81,7 @@ struct PtContext {
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
     int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
+    unsigned char* scratch_ptr = nullptr; // this device's address of `scratch` (hipGetSymbolAddress at context creation)
     int fused = 0;                // one path kernel per pass where it applies (measured: not faster, see path.hip)
     int repack_every = 0, repack_first = 8;  // measured on Cornell 1080p: the copy costs more than the fuller waves save
     std::vector<hipEvent_t> events;
@@ -96,6 +103,25 @@ struct PtContext {
     } while (0)
 
 namespace {
+
+// Address of `scratch` on `device`, which must be the current device: looked up once per device, then remembered.
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[256] = {};
+hipError_t scratch_for_device(int device, unsigned char** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    const bool cached = device >= 0 && device < 256;
+    if (cached && g_scratch_ptr[device]) {
+        *out = g_scratch_ptr[device];
+        return hipSuccess;
+    }
+    void* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    if (cached) g_scratch_ptr[device] = (unsigned char*)p;
+    *out = (unsigned char*)p;
+    return hipSuccess;
+}
 
 void free_buf(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
@@ -289,6 +315,12 @@ int pt_context_create(int device, PtContext** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
+    e = scratch_for_device(device, &ctx->scratch_ptr); // (this device is current: hipSetDevice above)
+    if (e != hipSuccess) {
+        g_last_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+        pt_context_destroy(ctx);
+        return PT_ERR_HIP;
+    }
     *out = ctx;
     return PT_OK;
 }
@@ -779,6 +811,37 @@ int pt_trace_batch(PtContext* ctx, const double* origins, const double* dirs, si
     free_buf(d_d);
     free_buf(d_out);
     return rc;
+}
+
+// pt_trace_batch without a single allocation: the rays and the hit records are staged in this device's copy of `scratch`
+// (reached through ctx->scratch_ptr, never through the array's name).  Nothing in there has to start at zero: the copies
+// fill [0, n) of the two input areas, the kernel reads and writes only [0, n), and the copy back takes only [0, n).
+int pt_trace_batch_static(PtContext* ctx, const double* origins, const double* dirs, size_t n, double t_min, double t_max,
+                          PtHitOut* out) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    if (!ctx->has_scene) return ctx->fail(PT_ERR_NO_SCENE, "pt_trace_batch_static: no scene uploaded");
+    if (n > PT_TRACE_STATIC_MAX_RAYS)
+        return ctx->fail(PT_ERR_BAD_ARG, "pt_trace_batch_static: n exceeds PT_TRACE_STATIC_MAX_RAYS (" + std::to_string(PT_TRACE_STATIC_MAX_RAYS) +
+                                             " rays fit the library's fixed scratch array); split the batch or use pt_trace_batch");
+    if (n == 0) return PT_OK;
+    if (!origins || !dirs || !out) return ctx->fail(PT_ERR_BAD_ARG, "pt_trace_batch_static: null array");
+    if (!ctx->scratch_ptr) return ctx->fail(PT_ERR_STATE, "pt_trace_batch_static: no scratch address for this device");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    static_assert(sizeof(PtHitOut) == 40, "scratch layout assumes 40-byte hit records");
+    double* d_o = reinterpret_cast<double*>(ctx->scratch_ptr);
+    double* d_d = reinterpret_cast<double*>(ctx->scratch_ptr + (size_t)PT_TRACE_STATIC_MAX_RAYS * 24u);
+    PtHitOut* d_out = reinterpret_cast<PtHitOut*>(ctx->scratch_ptr + (size_t)PT_TRACE_STATIC_MAX_RAYS * 48u);
+    hipError_t e = hipMemcpyAsync(d_o, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_d, dirs, n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        launch_trace_batch(ctx->stream, ctx->geom, ctx->sc, d_o, d_d, (uint32_t)n, t_min, t_max, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(PtHitOut), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t drained = hipStreamSynchronize(ctx->stream); // whatever was enqueued has finished before the call returns
+    if (e == hipSuccess) e = drained;
+    if (e != hipSuccess) return ctx->fail_hip("pt_trace_batch_static", e);
+    return PT_OK;
 }
 
 int pt_accum_reset(PtContext* ctx, uint32_t width, uint32_t height) {
