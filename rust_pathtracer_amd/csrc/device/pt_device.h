@@ -807,6 +807,7 @@ struct StreamWalk {
 // Correctness never rests on the guide tree being good, only on its boxes containing their primitives.
 #define PT_GUIDE_LEAF 0x80000000u
 #define PT_GUIDE_STACK 20 /* 20 KB of LDS per block: six blocks of the tail kernel (path.hip) fit a CU; deeper => literal walk */
+#define PT_GUIDE_ABS_SLACK 1e-37f /* see OrderedWalk::guide_slab */
 enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4 };
 struct OrderedScene { // wave-uniform: what the ordered walk reads
     const unsigned char* guide;  // guide tree: guide_nodes records of 64 bytes, node 0 = root
@@ -825,6 +826,10 @@ struct OrderedWalk {
     uint32_t best_parent; // stream offset of the node that is the best primitive's parent in the reference's tree
     uint32_t cur;         // LEAF: stream offset of the fetched record
     uint32_t mode, sp;
+    // The ray for the guide tree's box tests, in f32 (guide_slab): the origin as a rounded value plus its residual
+    // (of + rf = o to 2^-48 |o|), the reciprocal direction, and t_min moved down.
+    float of[3], rf[3], invf[3];
+    float tminf;
 #ifdef PT_DEBUG_STEPS
     uint32_t steps_guide, steps_leaf, steps_verify, went_literal;
 #endif
@@ -891,8 +896,8 @@ struct OrderedWalk {
         w.steps_nodes = w.steps_leaves = 0;
         steps_guide = steps_leaf = steps_verify = went_literal = 0;
 #endif
-        // Ordinary rays only: direction components in [2^-100, 2^100], origin within 2^100.  Then (with the scene's
-        // coordinates finite and below 1e37, checked at upload) no primitive test and no box test can overflow or produce
+        // Ordinary rays only: direction components in [2^-60, 2^100], origin within the scene's limit (at most 1e18).  Then (with
+        // the scene's coordinates finite and below 1e18, checked at upload) no primitive test and no box test can overflow or produce
         // a NaN, which is what the guide's arithmetic, the nesting argument AND the premise "a primitive that reports a
         // hit is crossed inside its box" rest on: the reference accepts a sphere whose discriminant is inf - inf = NaN
         // (geometry.rs:132-148: every comparison with NaN is false) wherever the ray is, and a NaN bound then lets any
@@ -903,35 +908,64 @@ struct OrderedWalk {
         // sizes of the scene's primitives into the two limits below (origin_limit <= 2^100).  All other rays take the
         // literal walk.
         const double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
-        const bool ordinary = fabs(w.inv.x) <= 0x1p100 && fabs(w.inv.y) <= 0x1p100 && fabs(w.inv.z) <= 0x1p100 && fabs(w.inv.x) >= 0x1p-100 &&
+        const bool ordinary = fabs(w.inv.x) <= 0x1p60 && fabs(w.inv.y) <= 0x1p60 && fabs(w.inv.z) <= 0x1p60 && fabs(w.inv.x) >= 0x1p-100 &&
                               fabs(w.inv.y) >= 0x1p-100 && fabs(w.inv.z) >= 0x1p-100 && omax <= sc.origin_limit &&
                               (omax + sc.tri_extent) * dmax <= sc.od_limit && t_min == t_min && t_max_ == t_max_;
+        const double oc[3] = {o.x, o.y, o.z}, ic[3] = {w.inv.x, w.inv.y, w.inv.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            of[k] = (float)oc[k];
+            rf[k] = (float)(oc[k] - (double)of[k]); // the difference is exact in f64; its rounding errs by 2^-48 |o|
+            invf[k] = (float)ic[k];
+        }
+        tminf = f32_not_above(t_min) - 2.0f * PT_GUIDE_ABS_SLACK;
         advance(sc, nullptr, ordinary, 0u, !ordinary);
     }
-    // one child's box against the ray: entry and exit parameters, each moved outwards by 1e-9 of itself
-    __device__ __forceinline__ bool guide_slab(float lx, float ly, float lz, float hx, float hy, float hz, double bound, double& entry) const {
-        const double ax = ((double)lx - w.o.x) * w.inv.x, bx = ((double)hx - w.o.x) * w.inv.x;
-        const double ay = ((double)ly - w.o.y) * w.inv.y, by = ((double)hy - w.o.y) * w.inv.y;
-        const double az = ((double)lz - w.o.z) * w.inv.z, bz = ((double)hz - w.o.z) * w.inv.z;
-        double tn = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-        double tf = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
-        tn = fma(fabs(tn), -1e-9, tn);
-        tf = fma(fabs(tf), 1e-9, tf);
+    // ---- The guide tree's box test, in f32.  It only has to be CONSERVATIVE: accept every child box (stored as f32, rounded
+    // outwards, padded by 1e-5 of the leaf's largest coordinate m) that the ray crosses within [t_min, bound]; what it
+    // accepts beyond that costs time, never correctness.  With u = 2^-24:
+    //   (l - o)      as (l - of) - rf: each subtraction rounds by u of its result, the residual's rounding adds 2^-48 |o|, an
+    //                absolute shift of the plane far inside the padding (begin() admits |o| <= 1e9 m only): relative error 2u;
+    //   * invf       invf = fl(inv) and the product round by u each: a slab parameter is off by at most 4u = 2.4e-7 of itself,
+    //                plus 2^-149 where the product underflows; no product overflows (the upload refuses a guide tree for
+    //                coordinates beyond 1e18, begin() admits |1/d| <= 2^60 only), so there is no inf and no NaN;
+    //   min / max    exact.
+    // Entry and exit are therefore moved outwards by 4e-7 of themselves, the bound (near(best) rounded to f32) up and t_min
+    // down by 2^-23 of themselves, and PT_GUIDE_ABS_SLACK covers every underflow (of a product, or of a conversion to f32).
+    // An f32 operation issues in 2.4 cycles per wave where an f64 one takes 4.2 (profiles/r01_instruction_rates.txt); the
+    // two boxes of a step cost ~50 of them instead of ~66 f64 ones plus twelve f32->f64 conversions.
+    static __device__ __forceinline__ float f32_not_below(double x) { // >= x (x finite or +inf)
+        const float f = (float)x;
+        return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f);
+    }
+    static __device__ __forceinline__ float f32_not_above(double x) {
+        const float f = (float)x;
+        return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f);
+    }
+    __device__ __forceinline__ bool guide_slab(float lx, float ly, float lz, float hx, float hy, float hz, float bound, float& entry) const {
+        const float ax = ((lx - of[0]) - rf[0]) * invf[0], bx = ((hx - of[0]) - rf[0]) * invf[0];
+        const float ay = ((ly - of[1]) - rf[1]) * invf[1], by = ((hy - of[1]) - rf[1]) * invf[1];
+        const float az = ((lz - of[2]) - rf[2]) * invf[2], bz = ((hz - of[2]) - rf[2]) * invf[2];
+        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+        tn = __builtin_fmaf(__builtin_fabsf(tn), -4e-7f, tn);
+        tf = __builtin_fmaf(__builtin_fabsf(tf), 4e-7f, tf);
         entry = tn;
-        return tn <= fmin(tf, bound) && tf >= w.t_min;
+        return tn - 2.0f * PT_GUIDE_ABS_SLACK <= __builtin_fminf(tf, bound) && tf >= tminf;
     }
     __device__ __forceinline__ void step_guide(const OrderedScene& sc, uint32_t* stack) {
 #ifdef PT_DEBUG_STEPS
         steps_guide += 1;
 #endif
-        const double bound = near(w.best_t);
+        // near(best) = best (1 + 1e-9) is what the argument needs the culling bound to reach; 2^-23 more covers the rounding to f32
+        const float bound = f32_not_below(near(w.best_t)) + PT_GUIDE_ABS_SLACK;
         float f[12];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             f[2 * k] = __int_as_float(__double2loint(w.g[k]));
             f[2 * k + 1] = __int_as_float(__double2hiint(w.g[k]));
         }
-        double e0, e1;
+        float e0, e1;
         const bool h0 = guide_slab(f[0], f[1], f[2], f[3], f[4], f[5], bound, e0);
         const bool h1 = guide_slab(f[6], f[7], f[8], f[9], f[10], f[11], bound, e1);
         const uint32_t c0 = w.kind, c1 = w.aux;

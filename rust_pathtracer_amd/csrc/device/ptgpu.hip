@@ -552,7 +552,11 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     //   rectangle in-plane error ~ 2^-51 (|o| + extent) <= 1e-5 m             if  |o|inf <= 2e10 m - extent
     //   triangle  barycentric error <= 1e-15 |o - p1| |d| |e| / det with det >= 1e-4 (geometry.rs:526), times the other edge:
     //             <= 1e-5 m  if  (|o|inf + extent of the triangles) |d|inf <= 8e4 / max(|e1| |e2| / m)
-    double ow_origin_limit = 0x1p100, ow_tri_ratio = 0.0, ow_tri_extent = 0.0, ow_rect_m = INFINITY, ow_rect_extent = 0.0;
+    // The guide tree's box tests run in f32 (pt_device.h guide_slab): the origin's f32 residual errs by 2^-48 |o|, which the
+    // padding of EVERY leaf must cover: |o|inf <= 1e9 * (smallest m over the leaves); and no slab product may overflow f32:
+    // coordinates and origins within 1e18 (with |1/d| <= 2^60).
+    double ow_origin_limit = 1e18, ow_tri_ratio = 0.0, ow_tri_extent = 0.0, ow_rect_m = INFINITY, ow_rect_extent = 0.0;
+    double ow_leaf_m_min = INFINITY, ow_leaf_m_max = 0.0;
     {
         auto leaf_box = [&](const double* lo, const double* hi) {
             GuideLeaf l;
@@ -562,6 +566,8 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
             guide_leaves.push_back(l);
             double m = 0.0;
             for (int q = 0; q < 3; ++q) m = std::max(m, std::max(std::fabs(lo[q]), std::fabs(hi[q])));
+            ow_leaf_m_min = std::min(ow_leaf_m_min, m);
+            ow_leaf_m_max = std::max(ow_leaf_m_max, m);
             return m; // the leaf's largest coordinate: what its padding is proportional to
         };
         // (parent_word: for primitive records of a stream built for the ordered walk, where the parent node's record starts)
@@ -699,7 +705,8 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     }
     std::vector<GuideNode> guide_nodes;
     if (boxes_nested) walk_flags |= PT_WALK_BOXES_NESTED;
-    const bool has_guide = want_guide && boxes_nested && walk.size() * sizeof(uint64_t) < 0x80000000ull && guide::build(guide_leaves, guide_nodes);
+    const bool has_guide = want_guide && boxes_nested && ow_leaf_m_max <= 1e18 && walk.size() * sizeof(uint64_t) < 0x80000000ull &&
+                           guide::build(guide_leaves, guide_nodes);
     if (has_guide) {
         PT_HIP(ctx, ensure_buf(ctx->d_guide, guide_nodes.size() * sizeof(GuideNode)));
         PT_HIP(ctx, hipMemcpy(ctx->d_guide.p, guide_nodes.data(), guide_nodes.size() * sizeof(GuideNode), hipMemcpyHostToDevice));
@@ -744,6 +751,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds
     sc.walk_flags = walk_flags;
     if (std::isfinite(ow_rect_m)) ow_origin_limit = std::min(ow_origin_limit, 2e10 * ow_rect_m - ow_rect_extent);
+    if (std::isfinite(ow_leaf_m_min)) ow_origin_limit = std::min(ow_origin_limit, 1e9 * ow_leaf_m_min);
     sc.ow_origin_limit = ow_origin_limit == ow_origin_limit ? ow_origin_limit : -1.0; // (negative or NaN: no ray qualifies)
     sc.ow_tri_extent = ow_tri_extent;
     sc.ow_od_limit = ow_tri_ratio > 0.0 ? 8e4 / ow_tri_ratio : __builtin_huge_val();
