@@ -8,7 +8,8 @@
 //
 // Node = 64 bytes, laid out like a stream record so that one fetch routine serves both:
 //   u32 child[2]            PT_GUIDE_LEAF | byte offset of a primitive record in the stream, or a node index
-//   f32 box[2][6]           the children's boxes (lo.xyz, hi.xyz), rounded outwards, padded (see pad())
+//   f32 box[2][6]           the children's boxes as (lo, hi) pairs per axis -- lo.x, hi.x, lo.y, hi.y, lo.z, hi.z: one packed
+//                           f32 operation handles both planes of an axis -- rounded outwards, padded (see pad())
 //   u32 unused[2]
 #pragma once
 #include <algorithm>
@@ -170,8 +171,8 @@ inline bool build(std::vector<GuideLeaf>& leaves, std::vector<GuideNode>& nodes)
             GuideNode& p = nodes[t.parent];
             p.child[t.slot] = ref;
             for (int k = 0; k < 3; ++k) {
-                p.box[t.slot][k] = round_down(whole.lo[k]);
-                p.box[t.slot][3 + k] = round_up(whole.hi[k]);
+                p.box[t.slot][2 * k] = round_down(whole.lo[k]);
+                p.box[t.slot][2 * k + 1] = round_up(whole.hi[k]);
             }
         }
     }

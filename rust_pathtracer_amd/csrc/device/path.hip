@@ -128,12 +128,12 @@ struct TailArgs {
 };
 
 #ifndef PT_TAIL_WAVES
-#define PT_TAIL_WAVES 6
+#define PT_TAIL_WAVES 5
 #endif
 template <int PROCEDURAL, bool TABLE_LDS>
-// (The persistent grid of an ordered-walk scene is 6 blocks per CU; a tail kernel of which only 4 fit runs them in two rounds,
-// i.e. twice the longest path.  Where LDS allows -- tables in global memory, no marble -- the kernel is therefore held to 80
-// VGPRs, spilling a few dozen rarely-used values: 1M-triangle mesh, 64 spp: 54.2 -> 49.4 ms/frame.)
+// (Occupancy: where LDS allows -- tables in global memory, no marble -- the kernel is held to 96 VGPRs = five waves per SIMD at
+// the price of ~28 spilled values; 1M-triangle mesh, 1080p 64 spp, ms/frame: 47.8 at five waves, 48.0 at four (112 VGPRs, no
+// spills), 60.1 at six (80 VGPRs, 60-100 spills: scratch traffic on the critical path of every step).)
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu((TABLE_LDS || PROCEDURAL == PT_PROC_MARBLE) ? 1 : PT_TAIL_WAVES)))
 void tail_kernel(DevScene sc, TailArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];

@@ -808,7 +808,7 @@ struct StreamWalk {
 #define PT_GUIDE_LEAF 0x80000000u
 #define PT_GUIDE_STACK 20 /* 20 KB of LDS per block: six blocks of the tail kernel (path.hip) fit a CU; deeper => literal walk */
 #define PT_GUIDE_ABS_SLACK 1e-37f /* see OrderedWalk::guide_slab */
-enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4 };
+enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4, PT_OW_LITERAL_BEGIN = 5 };
 struct OrderedScene { // wave-uniform: what the ordered walk reads
     const unsigned char* guide;  // guide tree: guide_nodes records of 64 bytes, node 0 = root
     const unsigned char* stream; // record stream with parent links, padded by 128 bytes
@@ -818,22 +818,39 @@ struct OrderedScene { // wave-uniform: what the ordered walk reads
 __host__ __device__ inline OrderedScene ordered_scene(const DevScene& sc) {
     return OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes, sc.ow_origin_limit, sc.ow_tri_extent, sc.ow_od_limit};
 }
+typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
+// What is the same for every ray of a kernel (wave-uniform: it lives in scalar registers, not once per lane).
+struct OrderedBounds {
+    double t_min, t_max; // the caller's window (ray.rs:25: 0.001, +inf)
+    float tmin_dn;       // t_min moved down for the guide tree's f32 box tests
+};
 struct OrderedWalk {
-    StreamWalk w;     // the ray, t_min, the best hit so far, and the fetched 56 bytes (kind, aux, g[6])
+    StreamWalk w;     // the ray, the best hit so far, and the fetched 56 bytes (kind, aux, g[6]); w.inv and w.t_min are set by
+                      // the literal step only (no lane carries six registers of reciprocals through the guide traversal)
     uint2 tail;       // bytes 56..63 of the fetch (triangle: the 7th double)
-    double t_max;     // the caller's bound (for LITERAL)
-    double second_t;  // nearest candidate other than the best one
+    // (second_t, the nearest candidate other than the best one, lives in q[4].y as an f32 rounded DOWN: a candidate is then
+    // taken for a near tie -- and the ray handed to the literal walk -- within 1.2e-7 of the best hit instead of 1e-9)
     uint32_t best_parent; // stream offset of the node that is the best primitive's parent in the reference's tree
     uint32_t cur;         // LEAF: stream offset of the fetched record
     uint32_t mode, sp;
-    // The ray for the guide tree's box tests, in f32 (guide_slab): the origin as a rounded value plus its residual
-    // (of + rf = o to 2^-48 |o|), the reciprocal direction, and t_min moved down.
-    float of[3], rf[3], invf[3];
-    float tminf;
+    // The ray for the guide tree's box tests, in f32 (guide_slab): the origin rounded, the reciprocal direction, and
+    // -(o - of) * invf, so that a slab parameter (l - o) / d is one subtraction and one fused multiply-add.
+    pt_f32x2 q[5]; // (of.x, of.y) (of.z, invf.x) (invf.y, invf.z) (nrinv.x, nrinv.y) (nrinv.z, second_t): see guide_slab
 #ifdef PT_DEBUG_STEPS
     uint32_t steps_guide, steps_leaf, steps_verify, went_literal;
 #endif
     static __device__ __forceinline__ double near(double b) { return fma(fabs(b), 1e-9, b); }
+    static __device__ __forceinline__ float f32_not_below(double x) { // >= x (x finite or +inf), up to PT_GUIDE_ABS_SLACK where the conversion underflows
+        const float f = (float)x;
+        return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f);
+    }
+    static __device__ __forceinline__ float f32_not_above(double x) {
+        const float f = (float)x;
+        return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f);
+    }
+    static __device__ __forceinline__ OrderedBounds bounds(double t_min, double t_max) {
+        return OrderedBounds{t_min, t_max, f32_not_above(t_min) - 2.0f * PT_GUIDE_ABS_SLACK};
+    }
     __device__ __forceinline__ void fetch64(const unsigned char* __restrict__ p) {
         const uint2 hdr = *reinterpret_cast<const uint2*>(p);
         const double2* q = reinterpret_cast<const double2*>(p + 8u);
@@ -845,7 +862,7 @@ struct OrderedWalk {
     // Where the lane goes next, and ONE fetch for it (the four destinations differ only in an address):
     //   `ref` if `have`, else the top of the stack, else -- the guide traversal is over -- nowhere (nothing was hit:
     //   the reference misses as well), the literal walk (a tie, or `literal` forced), or P's parent box.
-    __device__ __forceinline__ void advance(const OrderedScene& sc, const uint32_t* stack, bool have, uint32_t ref, bool literal) {
+    __device__ __forceinline__ void advance(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B, bool have, uint32_t ref, bool literal) {
         if (!have && !literal && sp > 0) {
             sp -= 1;
             ref = stack[sp * PT_BLOCK];
@@ -857,12 +874,12 @@ struct OrderedWalk {
             off = ref & ~PT_GUIDE_LEAF;
             mode = leaf ? PT_OW_LEAF : PT_OW_GUIDE;
             cur = leaf ? off : cur;
-        } else if (!literal && w.best_prim < 0 && second_t == __builtin_huge_val()) {
+        } else if (!literal && w.best_prim < 0 && q[4].y == __builtin_huge_valf()) {
             mode = PT_OW_IDLE; // no primitive test reported anything
             off = 0;
-        } else if (literal || !(second_t > near(w.best_t))) {
-            mode = PT_OW_LITERAL; // StreamWalk::begin without recomputing the reciprocals; the root record is a node (kind word 0)
-            w.best_t = t_max;
+        } else if (literal || !((double)q[4].y > near(w.best_t))) {
+            mode = PT_OW_LITERAL_BEGIN; // StreamWalk::begin; the root record is a node (kind word 0)
+            w.best_t = B.t_max;
             w.best_prim = -1;
             w.off = 0;
             off = 0;
@@ -883,14 +900,11 @@ struct OrderedWalk {
         const unsigned char* p = mode == PT_OW_GUIDE ? sc.guide + (size_t)min(off, sc.guide_nodes - 1u) * 64u : sc.stream + min(off, sc.stream_bytes);
         if (mode != PT_OW_IDLE) fetch64(p);
     }
-    __device__ __forceinline__ void begin(const OrderedScene& sc, V3 o, V3 d, double t_min, double t_max_) {
+    __device__ __forceinline__ void begin(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B, V3 o, V3 d) {
         w.o = o; w.d = d;
-        w.inv = v3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
-        w.t_min = t_min; w.best_t = t_max_;
+        w.best_t = B.t_max;
         w.best_prim = -1;
         w.off = 0;
-        t_max = t_max_;
-        second_t = __builtin_huge_val();
         best_parent = 0; cur = 0; sp = 0;
 #ifdef PT_DEBUG_STEPS
         w.steps_nodes = w.steps_leaves = 0;
@@ -905,69 +919,75 @@ struct OrderedWalk {
         // primitive relative to the primitive's size: the tests cancel and report hits for rays that pass whole units
         // beside it (a sphere of radius 0.5 seen from 1e9 away), outside the 1e-5 padding of its guide box, where the
         // reference -- which tests it whenever its parent's box is crossed -- still takes the hit.  The upload turns the
-        // sizes of the scene's primitives into the two limits below (origin_limit <= 2^100).  All other rays take the
-        // literal walk.
-        const double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), dmax = fmax(fmax(fabs(d.x), fabs(d.y)), fabs(d.z));
-        const bool ordinary = fabs(w.inv.x) <= 0x1p60 && fabs(w.inv.y) <= 0x1p60 && fabs(w.inv.z) <= 0x1p60 && fabs(w.inv.x) >= 0x1p-100 &&
-                              fabs(w.inv.y) >= 0x1p-100 && fabs(w.inv.z) >= 0x1p-100 && omax <= sc.origin_limit &&
-                              (omax + sc.tri_extent) * dmax <= sc.od_limit && t_min == t_min && t_max_ == t_max_;
-        const double oc[3] = {o.x, o.y, o.z}, ic[3] = {w.inv.x, w.inv.y, w.inv.z};
+        // sizes of the scene's primitives into the two limits below.  All other rays take the literal walk.
+        const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+        const double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), dmax = fmax(fmax(ax, ay), az), dmin = fmin(fmin(ax, ay), az);
+        const bool ordinary = dmin >= 0x1p-60 && dmax <= 0x1p100 && omax <= sc.origin_limit && (omax + sc.tri_extent) * dmax <= sc.od_limit &&
+                              B.t_min == B.t_min && B.t_max == B.t_max;
+        const double oc[3] = {o.x, o.y, o.z}, dc[3] = {d.x, d.y, d.z};
+        float of[3], invf[3], nrinv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             of[k] = (float)oc[k];
-            rf[k] = (float)(oc[k] - (double)of[k]); // the difference is exact in f64; its rounding errs by 2^-48 |o|
-            invf[k] = (float)ic[k];
+            const float rf = (float)(oc[k] - (double)of[k]); // the difference is exact in f64; its rounding errs by 2^-48 |o|
+            invf[k] = __builtin_amdgcn_rcpf((float)dc[k]);   // 1/d to 3 * 2^-24 (conversion 2^-24, v_rcp_f32 one ulp)
+            nrinv[k] = -(rf * invf[k]);
         }
-        tminf = f32_not_above(t_min) - 2.0f * PT_GUIDE_ABS_SLACK;
-        advance(sc, nullptr, ordinary, 0u, !ordinary);
+        q[0].x = of[0]; q[0].y = of[1]; q[1].x = of[2]; q[1].y = invf[0]; q[2].x = invf[1]; q[2].y = invf[2];
+        q[3].x = nrinv[0]; q[3].y = nrinv[1]; q[4].x = nrinv[2]; q[4].y = __builtin_huge_valf(); // no second candidate yet
+        advance(sc, stack, B, ordinary, 0u, !ordinary);
     }
-    // ---- The guide tree's box test, in f32.  It only has to be CONSERVATIVE: accept every child box (stored as f32, rounded
-    // outwards, padded by 1e-5 of the leaf's largest coordinate m) that the ray crosses within [t_min, bound]; what it
-    // accepts beyond that costs time, never correctness.  With u = 2^-24:
-    //   (l - o)      as (l - of) - rf: each subtraction rounds by u of its result, the residual's rounding adds 2^-48 |o|, an
-    //                absolute shift of the plane far inside the padding (begin() admits |o| <= 1e9 m only): relative error 2u;
-    //   * invf       invf = fl(inv) and the product round by u each: a slab parameter is off by at most 4u = 2.4e-7 of itself,
-    //                plus 2^-149 where the product underflows; no product overflows (the upload refuses a guide tree for
-    //                coordinates beyond 1e18, begin() admits |1/d| <= 2^60 only), so there is no inf and no NaN;
-    //   min / max    exact.
-    // Entry and exit are therefore moved outwards by 4e-7 of themselves, the bound (near(best) rounded to f32) up and t_min
+    // ---- The guide tree's box test, in packed f32.  It only has to be CONSERVATIVE: accept every child box (stored as f32,
+    // rounded outwards, padded by 1e-5 of the leaf's largest coordinate m) that the ray crosses within [t_min, bound]; what
+    // it accepts beyond that costs time, never correctness.  A node stores a child's box as (lo, hi) pairs per axis, so one
+    // packed subtraction and one packed fused multiply-add give both slab parameters of an axis:
+    //     a = fma(l - of, invf, -(o - of) * invf)      with u = 2^-24:
+    //   l - of       rounds by u of itself; |l - of| <= |l - o| + u |o|;
+    //   invf         is 1/d to 3u (begin); the residual o - of is exact in f64, its f32 rounding and the product with invf
+    //                add 2u of the residual; the fma rounds once more by u;
+    //   together     a = (l - o)/d * (1 + 5u) + |1/d| * 3 u^2 |o|: a relative error of 3e-7 and a shift of the plane by
+    //                1.1e-14 |o|, far inside the padding (begin() admits |o| <= 5e8 m only), plus 2^-149 where a product
+    //                underflows.  No product overflows (the upload refuses a guide tree for coordinates beyond 1e18, begin()
+    //                admits |1/d| <= 2^60 only): no inf, no NaN.  min / max are exact.
+    // Entry and exit are therefore moved outwards by 5e-7 of themselves, the bound (near(best) rounded to f32) up and t_min
     // down by 2^-23 of themselves, and PT_GUIDE_ABS_SLACK covers every underflow (of a product, or of a conversion to f32).
-    // An f32 operation issues in 2.4 cycles per wave where an f64 one takes 4.2 (profiles/r01_instruction_rates.txt); the
-    // two boxes of a step cost ~50 of them instead of ~66 f64 ones plus twelve f32->f64 conversions.
-    static __device__ __forceinline__ float f32_not_below(double x) { // >= x (x finite or +inf)
-        const float f = (float)x;
-        return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f);
-    }
-    static __device__ __forceinline__ float f32_not_above(double x) {
-        const float f = (float)x;
-        return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f);
-    }
-    __device__ __forceinline__ bool guide_slab(float lx, float ly, float lz, float hx, float hy, float hz, float bound, float& entry) const {
-        const float ax = ((lx - of[0]) - rf[0]) * invf[0], bx = ((hx - of[0]) - rf[0]) * invf[0];
-        const float ay = ((ly - of[1]) - rf[1]) * invf[1], by = ((hy - of[1]) - rf[1]) * invf[1];
-        const float az = ((lz - of[2]) - rf[2]) * invf[2], bz = ((hz - of[2]) - rf[2]) * invf[2];
-        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-        tn = __builtin_fmaf(__builtin_fabsf(tn), -4e-7f, tn);
-        tf = __builtin_fmaf(__builtin_fabsf(tf), 4e-7f, tf);
+    // (Every VALU instruction, f32 or f64, takes a SIMD four cycles per wave; only the packed forms do two lanes' worth of
+    // f32 work in one: 12 packed + ~30 plain instructions for the two boxes of a step, against ~80 in f64.)
+    // (Written as instructions because the compiler materialises a broadcast operand of a packed operation as a register
+    // pair: nine constants of the ray would take eighteen registers.  Here they sit in five pairs -- (of.x, of.y), (of.z,
+    // invf.x), (invf.y, invf.z), (nrinv.x, nrinv.y), (nrinv.z, -) -- and op_sel picks the half both lanes of the operation read.)
+#define PT_PK_SLAB(out, planes, c_of, sel_of, c_inv, sel_inv, c_nr, sel_nr)                                                          \
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0," #sel_of "] op_sel_hi:[1," #sel_of "] neg_lo:[0,1] neg_hi:[0,1]\n\t"                    \
+        "v_pk_fma_f32 %0, %0, %3, %4 op_sel:[0," #sel_inv "," #sel_nr "] op_sel_hi:[1," #sel_inv "," #sel_nr "]"                       \
+        : "=&v"(out)                                                                                                                 \
+        : "v"(planes), "v"(c_of), "v"(c_inv), "v"(c_nr))
+    __device__ __forceinline__ bool guide_slab(pt_f32x2 x, pt_f32x2 y, pt_f32x2 z, float bound, float tmin_dn, float& entry) const {
+        pt_f32x2 tx, ty, tz;
+        PT_PK_SLAB(tx, x, q[0], 0, q[1], 1, q[3], 0);
+        PT_PK_SLAB(ty, y, q[0], 1, q[2], 0, q[3], 1);
+        PT_PK_SLAB(tz, z, q[1], 0, q[2], 1, q[4], 0);
+        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fminf(tz.x, tz.y));
+        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
+        tn = __builtin_fmaf(__builtin_fabsf(tn), -5e-7f, tn);
+        tf = __builtin_fmaf(__builtin_fabsf(tf), 5e-7f, tf);
         entry = tn;
-        return tn - 2.0f * PT_GUIDE_ABS_SLACK <= __builtin_fminf(tf, bound) && tf >= tminf;
+        return tn - 2.0f * PT_GUIDE_ABS_SLACK <= __builtin_fminf(tf, bound) && tf >= tmin_dn;
     }
-    __device__ __forceinline__ void step_guide(const OrderedScene& sc, uint32_t* stack) {
+    static __device__ __forceinline__ pt_f32x2 pair_of(double packed) {
+        pt_f32x2 r;
+        r.x = __int_as_float(__double2loint(packed));
+        r.y = __int_as_float(__double2hiint(packed));
+        return r;
+    }
+    __device__ __forceinline__ void step_guide(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
 #ifdef PT_DEBUG_STEPS
         steps_guide += 1;
 #endif
         // near(best) = best (1 + 1e-9) is what the argument needs the culling bound to reach; 2^-23 more covers the rounding to f32
         const float bound = f32_not_below(near(w.best_t)) + PT_GUIDE_ABS_SLACK;
-        float f[12];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            f[2 * k] = __int_as_float(__double2loint(w.g[k]));
-            f[2 * k + 1] = __int_as_float(__double2hiint(w.g[k]));
-        }
-        float e0, e1;
-        const bool h0 = guide_slab(f[0], f[1], f[2], f[3], f[4], f[5], bound, e0);
-        const bool h1 = guide_slab(f[6], f[7], f[8], f[9], f[10], f[11], bound, e1);
+        float e0, e1; // (the fetched 48 bytes: child 0's x, y, z pairs, then child 1's)
+        const bool h0 = guide_slab(pair_of(w.g[0]), pair_of(w.g[1]), pair_of(w.g[2]), bound, B.tmin_dn, e0);
+        const bool h1 = guide_slab(pair_of(w.g[3]), pair_of(w.g[4]), pair_of(w.g[5]), bound, B.tmin_dn, e1);
         const uint32_t c0 = w.kind, c1 = w.aux;
         const bool both = h0 && h1, swap = both && e1 < e0;
         const bool overflow = both && sp >= PT_GUIDE_STACK;
@@ -975,28 +995,28 @@ struct OrderedWalk {
             stack[sp * PT_BLOCK] = swap ? c0 : c1;
             sp += 1;
         }
-        advance(sc, stack, (h0 || h1) && !overflow, (swap || !h0) ? c1 : c0, overflow);
+        advance(sc, stack, B, (h0 || h1) && !overflow, (swap || !h0) ? c1 : c0, overflow);
     }
     // a candidate from a primitive test run with the bound near(best)
     __device__ __forceinline__ void consider(bool hit, double t, uint32_t prim, uint32_t link) {
         if (!hit) return;
         if (t != t) { // cannot happen for an ordinary ray (see begin); if it does, the literal walk decides
-            second_t = -__builtin_huge_val();
+            q[4].y = -__builtin_huge_valf();
         } else if (t < w.best_t || w.best_prim < 0) {
-            if (w.best_prim >= 0) second_t = fmin(second_t, w.best_t);
+            if (w.best_prim >= 0) q[4].y = __builtin_fminf(q[4].y, f32_not_above(w.best_t) - PT_GUIDE_ABS_SLACK);
             w.best_t = t; w.best_prim = (int32_t)prim; best_parent = link;
         } else {
-            second_t = fmin(second_t, t);
+            q[4].y = __builtin_fminf(q[4].y, f32_not_above(t) - PT_GUIDE_ABS_SLACK);
         }
     }
-    __device__ __forceinline__ void step_leaf(const OrderedScene& sc, const uint32_t* stack) {
+    __device__ __forceinline__ void step_leaf(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
 #ifdef PT_DEBUG_STEPS
         steps_leaf += 1;
 #endif
-        const double bound = w.best_prim < 0 ? t_max : near(w.best_t);
+        const double bound = w.best_prim < 0 ? B.t_max : near(w.best_t);
         const V3 o = w.o, d = w.d;
         const double* g = w.g;
-        const double t_min = w.t_min;
+        const double t_min = B.t_min;
         const uint32_t kind = w.kind & PT_WK_KIND_MASK, aux = w.aux, link = (w.kind >> PT_WK_LINK_SHIFT) * 8u;
         double t;
         if (kind == PT_WK_SPHERE) {
@@ -1023,16 +1043,17 @@ struct OrderedWalk {
         } else {
             consider(hit_rect(g, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux, link);
         }
-        advance(sc, stack, false, 0u, false);
+        advance(sc, stack, B, false, 0u, false);
     }
-    __device__ __forceinline__ void step_verify(const OrderedScene& sc) {
+    __device__ __forceinline__ void step_verify(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
 #ifdef PT_DEBUG_STEPS
         steps_verify += 1;
 #endif
-        // bvh.rs:18-35 on the box of P's parent node, with a bound the reference's cannot be below
-        const V3 o = w.o, inv = w.inv;
+        // bvh.rs:18-35 on the box of P's parent node, operation for operation (the reciprocals as the reference forms them at
+        // every node), with a bound the reference's cannot be below
+        const V3 o = w.o, inv = v3(1.0 / w.d.x, 1.0 / w.d.y, 1.0 / w.d.z);
         const double* g = w.g;
-        double lo = w.t_min, hi = fmin(near(w.best_t), t_max);
+        double lo = B.t_min, hi = fmin(near(w.best_t), B.t_max);
         double t0 = (g[0] - o.x) * inv.x, t1 = (g[3] - o.x) * inv.x;
         lo = fmax((inv.x < 0.0) ? t1 : t0, lo); hi = fmin((inv.x < 0.0) ? t0 : t1, hi);
         bool miss = hi <= lo;
@@ -1042,10 +1063,22 @@ struct OrderedWalk {
         t0 = (g[2] - o.z) * inv.z; t1 = (g[5] - o.z) * inv.z;
         lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
         miss |= hi <= lo;
-        if (miss || w.kind != PT_WK_NODE) advance(sc, nullptr, false, 0u, true);
+        if (miss || w.kind != PT_WK_NODE) advance(sc, stack, B, false, 0u, true);
         else mode = PT_OW_IDLE; // the reference reaches P: it returns (P, best_t)
     }
-    __device__ __forceinline__ void step_literal(const OrderedScene& sc) {
+    // A lane that turns to the literal walk has no more use for its guide stack: the ray's reciprocals (bvh.rs:22, formed
+    // by the reference at every node) are parked in its first six slots, once, and read back by every literal step.
+    __device__ __forceinline__ void step_literal(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
+        if (mode == PT_OW_LITERAL_BEGIN) {
+            const double ix = 1.0 / w.d.x, iy = 1.0 / w.d.y, iz = 1.0 / w.d.z;
+            stack[0 * PT_BLOCK] = (uint32_t)__double2loint(ix); stack[1 * PT_BLOCK] = (uint32_t)__double2hiint(ix);
+            stack[2 * PT_BLOCK] = (uint32_t)__double2loint(iy); stack[3 * PT_BLOCK] = (uint32_t)__double2hiint(iy);
+            stack[4 * PT_BLOCK] = (uint32_t)__double2loint(iz); stack[5 * PT_BLOCK] = (uint32_t)__double2hiint(iz);
+            mode = PT_OW_LITERAL;
+        }
+        w.t_min = B.t_min;
+        w.inv = v3(__hiloint2double((int)stack[1 * PT_BLOCK], (int)stack[0 * PT_BLOCK]), __hiloint2double((int)stack[3 * PT_BLOCK], (int)stack[2 * PT_BLOCK]),
+                   __hiloint2double((int)stack[5 * PT_BLOCK], (int)stack[4 * PT_BLOCK])); // parked by advance()
         if (w.at_node()) w.step_node(sc.stream, sc.stream_bytes);
         else w.step_leaf(sc.stream, sc.stream_bytes);
         if (w.off >= sc.stream_bytes) mode = PT_OW_IDLE;

@@ -21,15 +21,19 @@
 // are waiting for memory anyway.
 // `io` supplies ray k of this wave's n rays and takes its result: the render kernel's region of the ray stream, or a
 // slice of the caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
+#ifndef PT_ORD_VERIFY_LANES
+#define PT_ORD_VERIFY_LANES 12
+#endif
 template <class RayIo>
 __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
     uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
     uint32_t mine = 0;
+    const OrderedBounds B = OrderedWalk::bounds(t_min, t_max);
     OrderedWalk w;
 #ifdef PT_DEBUG_BOUNDS
     w.w.lim = sc.stream_bytes;
 #endif
-    w.begin(sc, v3(0, 0, 0), v3(1, 1, 1), t_min, t_max);
+    w.begin(sc, stack, B, v3(0, 0, 0), v3(1, 1, 1));
     w.mode = PT_OW_IDLE;
     for (;;) {
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE);
@@ -41,27 +45,29 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
                 mine = k;
                 V3 o, d;
                 io.load(k, o, d);
-                w.begin(sc, o, d, t_min, t_max);
+                w.begin(sc, stack, B, o, d);
             }
             next = min(n, next + n_idle);
         } else if (n_idle == 64u) {
             break;
         }
         const uint32_t mode_before = w.mode;
-        // box tests (guide steps and the one verification step) together, primitive tests together
-        const uint32_t n_box = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE || w.mode == PT_OW_VERIFY));
+        // One kind of step per round: guide-tree box tests, the proof step (it forms the ray's three reciprocals: run when
+        // enough lanes have gathered for it, or nothing else is left to do), primitive tests, or the literal walk.
+        const uint32_t n_guide = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE));
+        const uint32_t n_verify = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_VERIFY));
         const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
-        const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LITERAL));
-        if (n_box != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) {
+        const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode >= PT_OW_LITERAL));
+        if (n_verify >= PT_ORD_VERIFY_LANES || (n_verify != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u)) {
+            if (w.mode == PT_OW_VERIFY) w.step_verify(sc, stack, B);
+        } else if (n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) {
 #pragma unroll
-            for (int r = 0; r < PT_ORD_NODE_STEPS; ++r) {
-                if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack);
-                else if (w.mode == PT_OW_VERIFY) w.step_verify(sc);
-            }
-        } else if (n_leaf >= n_literal) {
-            if (w.mode == PT_OW_LEAF) w.step_leaf(sc, stack);
+            for (int r = 0; r < PT_ORD_NODE_STEPS; ++r)
+                if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack, B);
+        } else if (n_leaf != 0u && n_leaf >= n_literal) {
+            if (w.mode == PT_OW_LEAF) w.step_leaf(sc, stack, B);
         } else {
-            if (w.mode == PT_OW_LITERAL) w.step_literal(sc); // rare: one step per round keeps the kernel small
+            if (w.mode >= PT_OW_LITERAL) w.step_literal(sc, stack, B); // rare: one step per round keeps the kernel small
         }
         if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE) io.store(mine, w.w.o, w.w.d, w.result_t(), w.w.best_prim);
     }

@@ -552,8 +552,8 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     //   rectangle in-plane error ~ 2^-51 (|o| + extent) <= 1e-5 m             if  |o|inf <= 2e10 m - extent
     //   triangle  barycentric error <= 1e-15 |o - p1| |d| |e| / det with det >= 1e-4 (geometry.rs:526), times the other edge:
     //             <= 1e-5 m  if  (|o|inf + extent of the triangles) |d|inf <= 8e4 / max(|e1| |e2| / m)
-    // The guide tree's box tests run in f32 (pt_device.h guide_slab): the origin's f32 residual errs by 2^-48 |o|, which the
-    // padding of EVERY leaf must cover: |o|inf <= 1e9 * (smallest m over the leaves); and no slab product may overflow f32:
+    // The guide tree's box tests run in f32 (pt_device.h guide_slab): they shift a plane by up to 1.1e-14 |o|, which the
+    // padding of EVERY leaf must cover: |o|inf <= 5e8 * (smallest m over the leaves); and no slab product may overflow f32:
     // coordinates and origins within 1e18 (with |1/d| <= 2^60).
     double ow_origin_limit = 1e18, ow_tri_ratio = 0.0, ow_tri_extent = 0.0, ow_rect_m = INFINITY, ow_rect_extent = 0.0;
     double ow_leaf_m_min = INFINITY, ow_leaf_m_max = 0.0;
@@ -751,7 +751,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds
     sc.walk_flags = walk_flags;
     if (std::isfinite(ow_rect_m)) ow_origin_limit = std::min(ow_origin_limit, 2e10 * ow_rect_m - ow_rect_extent);
-    if (std::isfinite(ow_leaf_m_min)) ow_origin_limit = std::min(ow_origin_limit, 1e9 * ow_leaf_m_min);
+    if (std::isfinite(ow_leaf_m_min)) ow_origin_limit = std::min(ow_origin_limit, 5e8 * ow_leaf_m_min);
     sc.ow_origin_limit = ow_origin_limit == ow_origin_limit ? ow_origin_limit : -1.0; // (negative or NaN: no ray qualifies)
     sc.ow_tri_extent = ow_tri_extent;
     sc.ow_od_limit = ow_tri_ratio > 0.0 ? 8e4 / ow_tri_ratio : __builtin_huge_val();
@@ -1414,11 +1414,11 @@ int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uin
     if (!guide::build(leaves, nodes)) return PT_ERR_BAD_ARG;
     if (nodes.size() != n - 1) return PT_ERR_STATE;
     // depth-first: each entry carries the box its parent stored for it
-    struct Item { uint32_t ref; float box[6]; uint32_t depth; };
+    struct Item { uint32_t ref; float box[6]; uint32_t depth; }; // box: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z (GuideNode's layout)
     std::vector<Item> todo;
     std::vector<uint8_t> seen_leaf(n, 0), seen_node(nodes.size(), 0);
     const float inf = std::numeric_limits<float>::infinity();
-    todo.push_back({0u, {-inf, -inf, -inf, inf, inf, inf}, 1u});
+    todo.push_back({0u, {-inf, inf, -inf, inf, -inf, inf}, 1u});
     uint32_t deepest = 0;
     while (!todo.empty()) {
         const Item it = todo.back();
@@ -1429,7 +1429,7 @@ int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uin
             if (i >= n || seen_leaf[i]) return PT_ERR_STATE;
             seen_leaf[i] = 1;
             for (int k = 0; k < 3; ++k)  // the box lies inside what the parent stored for it
-                if (!((double)it.box[k] <= boxes[6 * i + k] && (double)it.box[3 + k] >= boxes[6 * i + 3 + k])) return PT_ERR_STATE;
+                if (!((double)it.box[2 * k] <= boxes[6 * i + k] && (double)it.box[2 * k + 1] >= boxes[6 * i + 3 + k])) return PT_ERR_STATE;
             continue;
         }
         if (it.ref >= nodes.size() || seen_node[it.ref]) return PT_ERR_STATE;
@@ -1439,7 +1439,7 @@ int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uin
             Item ch{nd.child[c], {}, it.depth + 1u};
             for (int k = 0; k < 6; ++k) ch.box[k] = nd.box[c][k];
             for (int k = 0; k < 3; ++k)  // nested: a child's box never sticks out of its parent's
-                if (ch.box[k] < it.box[k] || ch.box[3 + k] > it.box[3 + k]) return PT_ERR_STATE;
+                if (ch.box[2 * k] < it.box[2 * k] || ch.box[2 * k + 1] > it.box[2 * k + 1]) return PT_ERR_STATE;
             todo.push_back(ch);
         }
     }

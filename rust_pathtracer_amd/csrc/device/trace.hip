@@ -134,7 +134,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
 }
 
 #ifndef PT_ORDERED_WAVES
-#define PT_ORDERED_WAVES 1
+#define PT_ORDERED_WAVES 5
 #endif
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_ORDERED_WAVES))) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
                                                                  uint32_t n_waves, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
