@@ -12,12 +12,17 @@
 #define PT_PERLIN_LDS_TABLES 16
 #define PT_TEX_LDS_MAX 32
 // The block's auxiliary LDS area (`s_perlin` in the kernels): [Perlin permutation tables (marble only)][texture table]
+// [Perlin gradient table (marble only)]
 template <int PROCEDURAL>
 constexpr uint32_t shade_lds_perlin_bytes() { return PROCEDURAL == PT_PROC_MARBLE ? PT_PERLIN_LDS_TABLES * 256u : 0u; }
 template <int PROCEDURAL>
+constexpr uint32_t shade_lds_grad_offset() { return shade_lds_perlin_bytes<PROCEDURAL>() + PT_TEX_LDS_MAX * (uint32_t)sizeof(PtTexture); }
+template <int PROCEDURAL>
 constexpr uint32_t shade_lds_aux_bytes() {
-    return PROCEDURAL == PT_PROC_NONE ? 16u : shade_lds_perlin_bytes<PROCEDURAL>() + PT_TEX_LDS_MAX * (uint32_t)sizeof(PtTexture);
+    return PROCEDURAL == PT_PROC_NONE ? 16u
+                                      : shade_lds_grad_offset<PROCEDURAL>() + (PROCEDURAL == PT_PROC_MARBLE ? PT_PERLIN_GRAD_DOUBLES * 8u : 0u);
 }
+static_assert(shade_lds_grad_offset<PT_PROC_MARBLE>() % 8u == 0u, "the gradient table is read as doubles");
 
 // What is the same for every ray of a bounce.
 struct ShadeEnv {
@@ -60,7 +65,11 @@ __device__ __forceinline__ bool shade_stage_tables(const DevScene& sc, unsigned 
         uint32_t* dst = reinterpret_cast<uint32_t*>(s_perlin + shade_lds_perlin_bytes<PROCEDURAL>());
         for (uint32_t k = threadIdx.x; k < sc.n_textures * (uint32_t)(sizeof(PtTexture) / 4u); k += PT_BLOCK) dst[k] = src[k];
     }
-    if (TABLE_LDS || perlin_in_lds || textures_in_lds) __syncthreads();
+    if (PROCEDURAL == PT_PROC_MARBLE) { // the gradient table (always: 384 bytes)
+        double* dst = reinterpret_cast<double*>(s_perlin + shade_lds_grad_offset<PROCEDURAL>());
+        if (threadIdx.x < PT_PERLIN_GRAD_DOUBLES) dst[threadIdx.x] = kPerlinGradTable[threadIdx.x];
+    }
+    if (TABLE_LDS || perlin_in_lds || textures_in_lds || PROCEDURAL == PT_PROC_MARBLE) __syncthreads();
     return perlin_in_lds;
 }
 
@@ -118,8 +127,9 @@ __device__ __forceinline__ void shade_chunk(const DevScene& sc, const ShadeEnv& 
                     const PtTexture* textures = sc.n_textures <= PT_TEX_LDS_MAX
                                                     ? reinterpret_cast<const PtTexture*>(s_perlin + shade_lds_perlin_bytes<PROCEDURAL>())
                                                     : sc.textures;
-                    V3 c = perlin_in_lds ? texture_value_procedural<marble>(textures, sc.n_textures, s_perlin, sp.texture, p)
-                                         : texture_value_procedural<marble>(textures, sc.n_textures, sc.perlin, sp.texture, p);
+                    const double* grad = marble ? reinterpret_cast<const double*>(s_perlin + shade_lds_grad_offset<PROCEDURAL>()) : nullptr;
+                    V3 c = perlin_in_lds ? texture_value_procedural<marble>(textures, sc.n_textures, s_perlin, grad, sp.texture, p)
+                                         : texture_value_procedural<marble>(textures, sc.n_textures, sc.perlin, grad, sp.texture, p);
                     cr = (float)c.x; cg = (float)c.y; cb = (float)c.z;
                 }
                 if (emits) {
