@@ -334,7 +334,7 @@ def load_pmc(args_config, overridden):
         d = json.load(open(path))
     except Exception:
         return {}
-    return d.get(f"config{args_config}", d if args_config == 2 and "trace_kernel" in d else {})
+    return d.get(f"config{args_config}", d if args_config == 2 and "trace_kernel" in d else {})  # (round 1's file was config 2 alone)
 
 
 # ---------------------------------------------------------------------------------------------------------- main

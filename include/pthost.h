@@ -109,6 +109,12 @@ int pth_write_png(const char* path, uint32_t width, uint32_t height, const uint8
 int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_dir, uint32_t first_frame, uint32_t frame_stride,
                       uint32_t max_frames, uint32_t* frames_total, uint32_t* frames_written, double* seconds_render, double* seconds_write,
                       uint64_t* rays);
+/* Progress reporting of pth_render_frames (the reference draws an indicatif bar per frame, main.rs:42-49,73-75): `callback`
+ * is called from the calling thread after every rendered frame with the number of frames done so far, the number this call
+ * will render, the frame index just finished and the seconds its render took.  NULL (the default) = no reporting.
+ * Process-wide; set it before the call. */
+typedef void (*PthProgressFn)(uint32_t frames_done, uint32_t frames_to_do, uint32_t frame_index, double frame_seconds, void* user);
+void pth_set_progress_callback(PthProgressFn callback, void* user);
 /* BASELINE.json configs[4] asks for the world to be rebuilt and uploaded for every frame (the reference builds it once,
  * main.rs:23).  on = 1: pth_render_frames runs scene.get_world() (BvhNode::new, same seeds, hence the same tree) and the
  * upload before each frame; the time that takes is kept apart from seconds_render and read back with

@@ -160,6 +160,8 @@ class PthObjectDesc(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("material", C.c_uint32), ("p", C.c_double * 12)]
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.c_void_p)
+
 # ------------------------------------------------------------------ prototypes: every symbol the headers declare
 _vp = C.c_void_p
 _PTGPU_PROTOS = {
@@ -223,6 +225,7 @@ _PTHOST_PROTOS = {
     "pth_write_png": (C.c_int, [C.c_char_p, C.c_uint32, C.c_uint32, _vp]),
     "pth_render_frames": (C.c_int, [_vp, C.c_int, C.c_uint64, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "pth_set_progress_callback": (None, [_vp, _vp]),
     "pth_scene_set_rebuild_per_frame": (C.c_int, [_vp, C.c_int]),
     "pth_scene_rebuild_seconds": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pth_obj_probe": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
@@ -371,18 +374,26 @@ class Scene:
         return out, stats
 
     def render_frames(self, out_dir: str, device: int = 0, seed: int = 0, first_frame: int = 0, frame_stride: int = 1, max_frames: int = 0,
-                      rebuild_per_frame: bool = False):
+                      rebuild_per_frame: bool = False, progress=None):
         """The frame loop of main.rs:24-72: renders the scene's frames (one for a static image) and writes
         out_dir/image_%04d.png, encoding each PNG while the next frame renders.  rebuild_per_frame: BvhNode::new and the
         upload again before every frame (BASELINE.json configs[4]); their time is reported apart."""
         total, written, rays = C.c_uint32(), C.c_uint32(), C.c_uint64()
         t_render, t_write, t_build, t_upload = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         self._ok(libpthost.pth_scene_set_rebuild_per_frame(self._h, 1 if rebuild_per_frame else 0))
-        self._ok(libpthost.pth_render_frames(self._h, device, seed, os.fsencode(out_dir), first_frame, frame_stride, max_frames,
-                                             C.byref(total), C.byref(written), C.byref(t_render), C.byref(t_write), C.byref(rays)))
+        cb = PROGRESS_FN(lambda done, todo, frame, seconds, _user: progress(done, todo, frame, seconds)) if progress else None
+        libpthost.pth_set_progress_callback(C.cast(cb, _vp) if cb else None, None)
+        try:
+            self._render_frames_call(device, seed, out_dir, first_frame, frame_stride, max_frames, total, written, t_render, t_write, rays)
+        finally:
+            libpthost.pth_set_progress_callback(None, None)
         self._ok(libpthost.pth_scene_rebuild_seconds(self._h, C.byref(t_build), C.byref(t_upload)))
         return {"frames_total": total.value, "frames_written": written.value, "seconds_render": t_render.value,
                 "seconds_write": t_write.value, "rays": rays.value, "seconds_build": t_build.value, "seconds_upload": t_upload.value}
+
+    def _render_frames_call(self, device, seed, out_dir, first_frame, frame_stride, max_frames, total, written, t_render, t_write, rays):
+        self._ok(libpthost.pth_render_frames(self._h, device, seed, os.fsencode(out_dir), first_frame, frame_stride, max_frames,
+                                             C.byref(total), C.byref(written), C.byref(t_render), C.byref(t_write), C.byref(rays)))
 
     # flattened tables as numpy views (copies), for tests
     def nodes_array(self) -> np.ndarray:

@@ -13,6 +13,8 @@ using namespace pt;
 
 namespace {
 thread_local std::string g_err;
+PthProgressFn g_progress = nullptr; // pth_set_progress_callback
+void* g_progress_user = nullptr;
 
 struct CustomScene : Scene { // a world built from an object list; no camera / settings of its own
     std::shared_ptr<BvhNode> world;
@@ -359,8 +361,15 @@ int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_di
             const double t0 = now();
             std::vector<uint8_t> pixels = r->render(s->scene->get_camera_at(t), im.width, im.height, im.background,
                                                     im.samples_per_pixel, im.max_bounces, seed, &st);
-            t_render += now() - t0;
+            const double frame_seconds = now() - t0;
+            t_render += frame_seconds;
             ray_sum += st.rays;
+            if (g_progress) {
+                const uint64_t remaining = (amount_of_frames - 1 - frame_index) / frame_stride; // frames after this one
+                uint64_t to_do = (uint64_t)written + 1 + remaining;
+                if (max_frames && to_do > max_frames) to_do = max_frames;
+                g_progress(written + 1, (uint32_t)to_do, (uint32_t)frame_index, frame_seconds, g_progress_user);
+            }
             if (writer.joinable()) writer.join();
             if (!write_error.empty()) throw std::runtime_error(write_error);
             const std::string path = frame_path(out_dir, (size_t)frame_index);
@@ -382,6 +391,11 @@ int pth_render_frames(PthScene* s, int device, uint64_t seed, const char* out_di
         if (seconds_write) *seconds_write = t_write;
         if (rays) *rays = ray_sum;
     });
+}
+
+void pth_set_progress_callback(PthProgressFn callback, void* user) {
+    g_progress = callback;
+    g_progress_user = user;
 }
 
 int pth_scene_set_rebuild_per_frame(PthScene* s, int on) {

@@ -128,12 +128,11 @@ int main(int argc, char** argv) {
         for (const char* bad : {"/selfcheck_bad1.obj", "/selfcheck_bad2.obj", "/selfcheck_bad3.obj", "/selfcheck_bad4.obj", "/selfcheck_bad5.obj", "/selfcheck_nope.obj"}) {
             uint32_t a = 0, b = 0;
             uint64_t t = 0;
-            const int rc = pth_obj_probe((tmp + bad).c_str(), &a, &t, &b); // must fail or succeed, never touch memory it does not own
+            (void)pth_obj_probe((tmp + bad).c_str(), &a, &t, &b); // must fail or succeed, never touch memory it does not own
             PthScene* q = pth_scene_create("ModelTest");
             if (pth_scene_set_model_path(q, (tmp + bad).c_str()) == 0) {
                 const int rb = pth_scene_build(q);
                 if (rb == 0) check_desc(pth_scene_desc(q));
-                CHECK(rc == 0 || rb != 0 || true);
             }
             pth_scene_destroy(q);
         }

@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     if (argc < 2) {
         std::fprintf(stderr,
                      "usage: ptrender SCENE [--width W --height H --spp N --depth D] [--out DIR] [--device I] [--seed S]\n"
-                     "                [--frames N] [--first-frame K --frame-stride M] [--rebuild-per-frame] [--model PATH | --synthetic-mesh NLON NLAT]\n"
+                     "                [--frames N] [--first-frame K --frame-stride M] [--rebuild-per-frame] [--quiet] [--model PATH | --synthetic-mesh NLON NLAT]\n"
                      "scenes: SphereField TwoSpheres LightTest CornellBox TriangleTest ModelTest\n");
         return 2;
     }
@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     std::string out = "./output", model;
     long width = 0, height = 0, spp = 0, depth = 0, device = 0, frames = 0, first = 0, stride = 1, nlon = 0, nlat = 0;
     unsigned long long seed = 1;
-    int rebuild = 0;
+    int rebuild = 0, quiet = 0;
     for (int i = 2; i < argc; ++i) {
         auto need = [&](int n) {
             if (i + n >= argc) {
@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--first-frame")) { need(1); first = std::atol(argv[++i]); }
         else if (!std::strcmp(argv[i], "--frame-stride")) { need(1); stride = std::atol(argv[++i]); }
         else if (!std::strcmp(argv[i], "--rebuild-per-frame")) { rebuild = 1; }
+        else if (!std::strcmp(argv[i], "--quiet")) { quiet = 1; }
         else if (!std::strcmp(argv[i], "--model")) { need(1); model = argv[++i]; }
         else if (!std::strcmp(argv[i], "--synthetic-mesh")) { need(2); nlon = std::atol(argv[++i]); nlat = std::atol(argv[++i]); }
         else {
@@ -75,6 +76,13 @@ int main(int argc, char** argv) {
     uint32_t total = 0, written = 0;
     double t_render = 0.0, t_write = 0.0;
     uint64_t rays = 0;
+    // main.rs:42-49,73-75 draws a progress bar per frame; here one line per frame on stderr (--quiet turns it off)
+    if (!quiet)
+        pth_set_progress_callback(
+            [](uint32_t done, uint32_t to_do, uint32_t frame, double seconds, void*) {
+                std::fprintf(stderr, "[%u/%u] frame %04u rendered in %.3f s\n", done, to_do, frame, seconds);
+            },
+            nullptr);
     if (pth_render_frames(s, (int)device, seed, out.c_str(), (uint32_t)first, (uint32_t)stride, (uint32_t)frames, &total, &written, &t_render,
                           &t_write, &rays) != 0)
         return fail("rendering");

@@ -245,6 +245,26 @@ def test_frame_loop_failure_raises_instead_of_terminating(pt, tmp_path):
     assert info["frames_written"] == 2
 
 
+def test_frame_loop_reports_progress(pt, tmp_path):
+    """main.rs:42-49: progress per frame -- here a callback (frames done, frames to do, frame index, seconds)."""
+    import subprocess
+
+    s = pt.Scene("SphereField").set_seeds(3, 3, 3).set_image(32, 16, 2, 4, (1, 1, 1)).build()
+    seen = []
+    info = s.render_frames(str(tmp_path), seed=3, first_frame=5, frame_stride=100, progress=lambda *a: seen.append(a))
+    assert info["frames_written"] == 3
+    assert [(d, n, f) for d, n, f, _ in seen] == [(1, 3, 5), (2, 3, 105), (3, 3, 205)] and all(sec > 0 for *_, sec in seen)
+    seen.clear()
+    s.render_frames(str(tmp_path), seed=3, first_frame=0, frame_stride=10, max_frames=2, progress=lambda *a: seen.append(a))
+    assert [(d, n, f) for d, n, f, _ in seen] == [(1, 2, 0), (2, 2, 10)]
+    exe = os.path.join(os.path.dirname(api.__file__), "bin", "ptrender")
+    args = [exe, "SphereField", "--width", "32", "--height", "16", "--spp", "2", "--depth", "4", "--out", str(tmp_path / "cli"), "--frame-stride", "150"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "[1/2] frame 0000" in r.stderr and "[2/2] frame 0150" in r.stderr, r.stderr
+    r = subprocess.run(args + ["--quiet"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "frame 0000" not in r.stderr
+
+
 def test_busy_times_are_unions_of_launch_intervals(pt):
     w, h, spp, depth = 256, 144, 12, 12
     s = pt.Scene("CornellBox").set_image(w, h, spp, depth, (0, 0, 0)).build()

@@ -346,3 +346,17 @@ def test_obj_reader_edge_cases(pt, tmp_path):
     (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
     with pytest.raises(pt.PtError):
         pt.Scene("ModelTest").set_model_path(str(tmp_path / "bad.obj"))
+
+
+def test_host_layer_is_clean_under_sanitizers():
+    """SURVEY.md section 5: the host code (scene builders, BvhNode::new, flattening, OBJ/MTL reader, PNG writer, C API error
+    paths) built with -fsanitize=address,undefined and driven by tools/host_selfcheck.cpp; any report aborts the run."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rust_pathtracer_amd")
+    r = subprocess.run(["make", "-C", pkg, "asan"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all checks passed" in r.stdout
