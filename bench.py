@@ -84,6 +84,9 @@ def parse_args():
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed lanes=1 frame")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--out-image", default=None, help="write the last frame as a PNG (config 1 always writes one)")
+    ap.add_argument("--devices", default=None, help="comma-separated device index per worker (default 0..N-1).  Listing a device twice "
+                    "rehearses the N-worker code path on a box with fewer GPUs: RCCL cannot reduce between two contexts of one device, "
+                    "so the buffers are then summed through the host and the line says so")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
     overridden = False
@@ -363,15 +366,20 @@ def main():
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    elif pt.device_count() < world:
-        raise SystemExit(f"--gpus {world} but only {pt.device_count()} visible")
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
+    if not per_process:
+        if len(devices) != world:
+            raise SystemExit(f"--devices lists {len(devices)} devices for --gpus {world}")
+        if max(devices) >= pt.device_count():
+            raise SystemExit(f"--gpus {world} needs devices {devices} but only {pt.device_count()} visible")
+    rehearsal = not per_process and len(set(devices)) < len(devices)
 
     animation = bool(cfg.get("frames"))
     w, h, spp, depth = cfg["width"], cfg["height"], cfg["spp"], cfg["depth"]
     if per_process:
         workers = [Worker(pt, args, cfg, local_rank, rank, world)]
     else:
-        workers = [Worker(pt, args, cfg, g, g, world) for g in range(world)]
+        workers = [Worker(pt, args, cfg, devices[g], g, world) for g in range(world)]
     root = workers[0]
     pool = ThreadPoolExecutor(max_workers=in_process) if in_process > 1 else None
     accum = None
@@ -401,27 +409,45 @@ def main():
             torch.cuda.synchronize()
         else:
             everyone("static_share")
-            if world > 1:
+            if world > 1 and not rehearsal:
                 pt.accum_reduce([wk.ctx for wk in workers])  # RCCL over xGMI, on the contexts' streams; returns when drained
+            elif world > 1:  # rehearsal on shared devices only: through the host
+                total = workers[0].ctx.accum_download()
+                for wk in workers[1:]:
+                    total = total + wk.ctx.accum_download()
+                root.ctx.accum_upload(total)
         if rank == 0:
             root.img = root.ctx.resolve(spp)
 
     def fence():
-        for g in ([local_rank] if per_process else range(world)):
+        for g in ([local_rank] if per_process else sorted(set(devices))):
             torch.cuda.synchronize(g)
         if per_process:
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Kernel timing (two HIP events around every launch) costs ~1 ms per frame: nothing against a 137 ms frame, 6 % of an 8-GPU
+    # share of it.  On one GPU every timed step is profiled; on N > 1 only GPU 0's first timed step is (still inside the timed
+    # region), the rest of the run carries no events.
+    profile_all = world == 1
+    if not profile_all:
+        for wk in workers:
+            wk.ctx.set_option("profile", 0)
     for _ in range(args.warmup):
         step()
     fence()
     t0 = time.perf_counter()
     stats_root, rays_local = [], 0
     seconds_build = seconds_upload = 0.0
-    for _ in range(args.steps):
+    profiled_steps = 0
+    for k in range(args.steps):
+        profiled = profile_all or (k == 0 and rank == 0)
+        if not profile_all:
+            root.ctx.set_option("profile", 1 if profiled else 0)
         step()
-        stats_root += root.stats
+        if profiled:
+            stats_root += root.stats
+            profiled_steps += 1
         rays_local += sum(st.rays for wk in workers for st in wk.stats)
         seconds_build += max(wk.seconds_build for wk in workers)
         seconds_upload += max(wk.seconds_upload for wk in workers)
@@ -436,6 +462,7 @@ def main():
         root.static_share()
         iso = sum_stats(root.stats)
         root.ctx.set_option("lanes", 0)  # the library default (automatic)
+    profiled_steps = max(1, profiled_steps)
 
     if per_process:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -448,7 +475,7 @@ def main():
         rays_total = rays_local
 
     if rank == 0:
-        props = torch.cuda.get_device_properties(local_rank if per_process else 0)
+        props = torch.cuda.get_device_properties(local_rank if per_process else devices[0])
         n_cus = props.multi_processor_count
         clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
         ms_per_step = elapsed / args.steps * 1e3
@@ -467,6 +494,7 @@ def main():
                         "frac": with_bytes["frac"], "traffic": with_bytes.get("traffic"), "traffic_source": with_bytes.get("traffic_source"),
                         "avg_launch_ms": with_bytes["avg_launch_ms"], "bytes_per_launch": with_bytes["bytes_per_launch"],
                         "dominant_by": "largest sum of launch durations in the timed region (GPU 0)",
+                        "profiled_steps": profiled_steps,
                         "kernels": kernels,
                         "pipeline_frac": round(mrays * 1e6 * BYTES_SEGMENT / world / (HBM_PEAK_GBS * 1e9), 5)}
             if iso is not None:
@@ -489,16 +517,18 @@ def main():
             "config": {"workload": cfg["label"],
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"frames mod {world}" if animation else f"spp-sharded x{world}, one RCCL reduce per frame")
-                                       + (", one process per GPU (torch.distributed)" if per_process else ", one process, one host thread per GPU (pt_accum_reduce)")),
+                                       + (", one process per GPU" + ("" if animation else " (torch.distributed reduce)") if per_process
+                                          else ", one process, one host thread per GPU" + ("" if animation else " (pt_accum_reduce)"))
+                                       + (" -- REHEARSAL: workers share a GPU, buffers summed through the host, not a multi-GPU measurement" if rehearsal else "")),
                        "rays_per_frame": rays_total // (args.steps * frames_per_step)},
             "roofline": roofline,
             "issue_roofline": issue_roofline(pmc, mrays / world, n_cus, clock_hz),
             # union of each kernel's launch intervals on GPU 0 (with several lanes launches overlap: the sums of launch
             # durations, roofline.kernels[].launch_ms_sum, can exceed the frame)
-            "kernel_busy_ms_per_step": {"trace": round(tot["ms_busy_trace"] / args.steps, 3), "shade": round(tot["ms_busy_shade"] / args.steps, 3),
-                                        "path": round(tot["ms_busy_path"] / args.steps, 3), "any_kernel": round(tot["ms_busy_all"] / args.steps, 3),
-                                        "raygen_sum": round(tot["ms_raygen"] / args.steps, 3), "fold_sum": round(tot["ms_fold"] / args.steps, 3),
-                                        "render_call": round(tot["ms_total"] / args.steps, 3)},
+            "kernel_busy_ms_per_step": {"trace": round(tot["ms_busy_trace"] / profiled_steps, 3), "shade": round(tot["ms_busy_shade"] / profiled_steps, 3),
+                                        "path": round(tot["ms_busy_path"] / profiled_steps, 3), "any_kernel": round(tot["ms_busy_all"] / profiled_steps, 3),
+                                        "raygen_sum": round(tot["ms_raygen"] / profiled_steps, 3), "fold_sum": round(tot["ms_fold"] / profiled_steps, 3),
+                                        "render_call": round(tot["ms_total"] / profiled_steps, 3)},
         }
         if root.stats:
             out["rays_per_bounce_last_call"] = [int(x) for x in list(root.stats[-1].rays_per_bounce)[:min(depth, 64)]]
