@@ -174,6 +174,9 @@ const char* pt_last_error(const PtContext* ctx);
  *   on the ordered walk, and for scenes on the lockstep walk with solid textures ("fused" = from bounce 0); -1 = automatic:
  *   4 for ordered-walk scenes of 65536 primitives or more, never otherwise (measured on the Cornell box: 20.5 / 21.3 / 22.2 ms
  *   per 32-spp frame for never / 16 / 12); results are identical),
+ * "guide_build" (who builds the ordered walk's guide tree at the next pt_scene_upload: 0 = the host, binned surface-area splits
+ *   (0.45 s for a million triangles; the default: its trees take ~25 % fewer steps per ray); 1 = the device, linear BVH
+ *   (milliseconds: for worlds rebuilt every frame); results are identical either way),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 
@@ -250,6 +253,9 @@ int pt_selftest_texture(PtContext* ctx, uint32_t tex, const double* points, size
  * (boxes[6*i .. 6*i+5] = lo.xyz, hi.xyz) and verifies that every box is a leaf exactly once and lies inside every box
  * stored on the way down to it.  Touches no device.  PT_ERR_BAD_ARG for unusable boxes, PT_ERR_STATE for a broken tree. */
 int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth);
+/* The same check of the DEVICE builder ("guide_build" 1: Morton sort + Karras hierarchy + bottom-up refit on ctx's GPU): the
+ * tree is built on the device, copied back and verified on the host. */
+int pt_selftest_guide_tree_device(PtContext* ctx, const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth);
 
 #ifdef __cplusplus
 }

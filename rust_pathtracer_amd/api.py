@@ -190,6 +190,7 @@ _PTGPU_PROTOS = {
     "pt_selftest_rng": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp]),
     "pt_selftest_texture": (C.c_int, [_vp, C.c_uint32, _vp, C.c_size_t, _vp]),
     "pt_selftest_guide_tree": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "pt_selftest_guide_tree_device": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 }
 _PTHOST_PROTOS = {
     "pth_last_error": (C.c_char_p, []),
@@ -517,6 +518,14 @@ class Context:
         q = np.empty_like(a)
         self._ok(libptgpu.pt_selftest_division(self._h, a.ctypes.data, b.ctypes.data, a.size, q.ctypes.data))
         return q
+
+    def selftest_guide_tree_device(self, boxes: np.ndarray):
+        """Builds the guide tree over boxes [n, 6] ON THE DEVICE and verifies it on the host; returns (nodes, depth)."""
+        b = np.ascontiguousarray(boxes, dtype=np.float64)
+        assert b.ndim == 2 and b.shape[1] == 6
+        n_nodes, depth = C.c_uint32(), C.c_uint32()
+        self._ok(libptgpu.pt_selftest_guide_tree_device(self._h, b.ctypes.data, b.shape[0], C.byref(n_nodes), C.byref(depth)))
+        return n_nodes.value, depth.value
 
     def selftest_rng(self, seed, pixel, sample, stream, n) -> np.ndarray:
         out = np.empty(n, dtype=np.float64)

@@ -66,11 +66,10 @@ inline float round_up(double v) {
     return ((double)f < v) ? std::nextafterf(f, INFINITY) : f;
 }
 
-// Returns false (no tree) when a leaf box is not finite or the stream is too long for a 31-bit offset.
-inline bool build(std::vector<GuideLeaf>& leaves, std::vector<GuideNode>& nodes) {
-    nodes.clear();
-    const size_t n = leaves.size();
-    if (n < 2) return false;
+// Whether a tree can be built over these leaves at all (by either builder): at least two, every box finite with lo <= hi and
+// within what survives the rounding to f32, every stream offset within 31 bits.
+inline bool usable(const std::vector<GuideLeaf>& leaves) {
+    if (leaves.size() < 2) return false;
     for (const GuideLeaf& l : leaves) {
         if (l.offset & PT_GUIDE_LEAF) return false;
         for (int k = 0; k < 3; ++k)
@@ -78,6 +77,14 @@ inline bool build(std::vector<GuideLeaf>& leaves, std::vector<GuideNode>& nodes)
         for (int k = 0; k < 3; ++k)
             if (std::fabs(l.lo[k]) > 1e37 || std::fabs(l.hi[k]) > 1e37) return false; // must survive the float rounding
     }
+    return true;
+}
+
+// The host builder: binned surface-area splits.  Returns false (no tree) when the leaves are not usable().
+inline bool build(std::vector<GuideLeaf>& leaves, std::vector<GuideNode>& nodes) {
+    nodes.clear();
+    const size_t n = leaves.size();
+    if (!usable(leaves)) return false;
     nodes.reserve(n - 1);
     std::vector<uint32_t> idx(n);
     for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;

@@ -15,6 +15,9 @@
 #include "guide_tree.h"
 #include "pt_launch.h"
 
+// guide_build.hip: the guide tree built on the device (option "guide_build")
+hipError_t guide_build_on_device(hipStream_t stream, const std::vector<GuideLeaf>& leaves, GuideNode* d_nodes, const char** reason);
+
 #define PT_MAX_LANES 8
 #ifndef PT_TAIL_FROM_DEFAULT
 #define PT_TAIL_FROM_DEFAULT 4u
@@ -82,6 +85,7 @@ struct PtContext {
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
     int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
     unsigned char* scratch_ptr = nullptr; // this device's address of `scratch` (hipGetSymbolAddress at context creation)
+    int guide_build_device = 0;   // 1: the ordered walk's guide tree is built on the device (guide_build.hip) instead of on the host
     int fused = 0;                // one path kernel per pass where it applies (measured: not faster, see path.hip)
     int repack_every = 0, repack_first = 8;  // measured on Cornell 1080p: the copy costs more than the fuller waves save
     std::vector<hipEvent_t> events;
@@ -381,6 +385,9 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
     } else if (k == "trace_mode") {  // -1 automatic, 0 lockstep walk, 1 per-lane stack (LDS), 2 per-lane record stream, 3 ordered; next upload
         if (value < -1 || value > 3) return ctx->fail(PT_ERR_BAD_ARG, "trace_mode out of range [-1, 3]");
         ctx->trace_mode_override = (int)value;
+    } else if (k == "guide_build") {  // 0: host, binned surface-area splits; 1: device, Morton sort + Karras hierarchy; next upload
+        if (value < 0 || value > 1) return ctx->fail(PT_ERR_BAD_ARG, "guide_build must be 0 (host) or 1 (device)");
+        ctx->guide_build_device = (int)value;
     } else if (k == "blocks_per_cu") {  // tuning knob: persistent-grid blocks (of 4 waves) per CU; takes effect at the next upload
         if (value < 0 || value > 16) return ctx->fail(PT_ERR_BAD_ARG, "blocks_per_cu out of range [0, 16]");
         ctx->blocks_per_cu_override = (int)value;
@@ -705,11 +712,24 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     }
     std::vector<GuideNode> guide_nodes;
     if (boxes_nested) walk_flags |= PT_WALK_BOXES_NESTED;
-    const bool has_guide = want_guide && boxes_nested && ow_leaf_m_max <= 1e18 && walk.size() * sizeof(uint64_t) < 0x80000000ull &&
-                           guide::build(guide_leaves, guide_nodes);
-    if (has_guide) {
+    const bool guide_possible = want_guide && boxes_nested && ow_leaf_m_max <= 1e18 && walk.size() * sizeof(uint64_t) < 0x80000000ull;
+    bool has_guide = false;
+    size_t n_guide_nodes = 0;
+    if (guide_possible && ctx->guide_build_device && guide::usable(guide_leaves)) {
+        n_guide_nodes = guide_leaves.size() - 1;
+        PT_HIP(ctx, ensure_buf(ctx->d_guide, n_guide_nodes * sizeof(GuideNode)));
+        const char* why = "";
+        hipError_t e = guide_build_on_device(ctx->stream, guide_leaves, (GuideNode*)ctx->d_guide.p, &why);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->stream);
+            return ctx->fail_hip(why, e);
+        }
+        has_guide = true;
+    } else if (guide_possible && guide::build(guide_leaves, guide_nodes)) {
+        n_guide_nodes = guide_nodes.size();
         PT_HIP(ctx, ensure_buf(ctx->d_guide, guide_nodes.size() * sizeof(GuideNode)));
         PT_HIP(ctx, hipMemcpy(ctx->d_guide.p, guide_nodes.data(), guide_nodes.size() * sizeof(GuideNode), hipMemcpyHostToDevice));
+        has_guide = true;
     }
     PT_HIP(ctx, ensure_buf(ctx->d_nodes, nodes.size() * sizeof(DevNode)));
     PT_HIP(ctx, ensure_buf(ctx->d_prims, prims.size() * sizeof(DevPrim)));
@@ -745,7 +765,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     // which kernel walks it: the wave-uniform walk while the stream fits the scalar cache, one lane per ray beyond
     // and, beyond that, in nearest-first order over the guide tree where one could be built
     sc.guide = has_guide ? (const unsigned char*)ctx->d_guide.p : nullptr;
-    sc.guide_nodes = has_guide ? (uint32_t)guide_nodes.size() : 0u;
+    sc.guide_nodes = has_guide ? (uint32_t)n_guide_nodes : 0u;
     sc.trace_mode = !large ? PT_TRACE_LOCKSTEP : (has_guide ? PT_TRACE_ORDERED : PT_TRACE_STREAM);
     if (ctx->trace_mode_override >= 0) sc.trace_mode = (uint32_t)ctx->trace_mode_override;
     if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds
@@ -1399,19 +1419,10 @@ int pt_selftest_texture(PtContext* ctx, uint32_t tex, const double* points, size
     return PT_OK;
 }
 
-// Host-only check of the guide-tree builder (guide_tree.h): builds the tree over n boxes (lo.xyz, hi.xyz each; box i stands for
-// the primitive record at stream offset 8 * i) and verifies it: every box is a leaf exactly once, every child box stored in a
-// node contains, after the outward rounding to f32, all the boxes below it.  No device is touched.
-int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth) {
-    if (!boxes || n < 2 || n > ((size_t)1 << 26)) return PT_ERR_BAD_ARG;
-    std::vector<GuideLeaf> leaves(n);
-    for (size_t i = 0; i < n; ++i) {
-        for (int k = 0; k < 3; ++k) { leaves[i].lo[k] = boxes[6 * i + k]; leaves[i].hi[k] = boxes[6 * i + 3 + k]; }
-        leaves[i].offset = (uint32_t)(8u * i);
-        guide::pad(leaves[i]);
-    }
-    std::vector<GuideNode> nodes;
-    if (!guide::build(leaves, nodes)) return PT_ERR_BAD_ARG;
+// Checks of the guide-tree builders (guide_tree.h on the host, guide_build.hip on the device): the tree over n boxes (lo.xyz,
+// hi.xyz each; box i stands for the primitive record at stream offset 8 * i) is verified on the host: every box is a leaf
+// exactly once, every child box stored in a node contains, after the outward rounding to f32, all the boxes below it.
+static int verify_guide_tree(const std::vector<GuideNode>& nodes, const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth) {
     if (nodes.size() != n - 1) return PT_ERR_STATE;
     // depth-first: each entry carries the box its parent stored for it
     struct Item { uint32_t ref; float box[6]; uint32_t depth; }; // box: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z (GuideNode's layout)
@@ -1447,6 +1458,46 @@ int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uin
         if (!seen_leaf[i]) return PT_ERR_STATE;
     if (n_nodes) *n_nodes = (uint32_t)nodes.size();
     if (max_depth) *max_depth = deepest;
+    return PT_OK;
+}
+static bool selftest_leaves(const double* boxes, size_t n, std::vector<GuideLeaf>& leaves) {
+    if (!boxes || n < 2 || n > ((size_t)1 << 26)) return false;
+    leaves.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) { leaves[i].lo[k] = boxes[6 * i + k]; leaves[i].hi[k] = boxes[6 * i + 3 + k]; }
+        leaves[i].offset = (uint32_t)(8u * i);
+        guide::pad(leaves[i]);
+    }
+    return true;
+}
+int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth) {
+    std::vector<GuideLeaf> leaves;
+    if (!selftest_leaves(boxes, n, leaves)) return PT_ERR_BAD_ARG;
+    std::vector<GuideNode> nodes;
+    if (!guide::build(leaves, nodes)) return PT_ERR_BAD_ARG;
+    return verify_guide_tree(nodes, boxes, n, n_nodes, max_depth);
+}
+int pt_selftest_guide_tree_device(PtContext* ctx, const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth) {
+    if (!ctx) return PT_ERR_BAD_ARG;
+    std::vector<GuideLeaf> leaves;
+    if (!selftest_leaves(boxes, n, leaves) || !guide::usable(leaves)) return ctx->fail(PT_ERR_BAD_ARG, "pt_selftest_guide_tree_device: unusable boxes");
+    PT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d;
+    hipError_t e = ensure_buf(d, (n - 1) * sizeof(GuideNode));
+    const char* why = "hipMalloc(guide nodes)";
+    std::vector<GuideNode> nodes(n - 1);
+    if (e == hipSuccess) e = guide_build_on_device(ctx->stream, leaves, (GuideNode*)d.p, &why);
+    if (e == hipSuccess) {
+        why = "hipMemcpy(guide nodes)";
+        e = hipMemcpy(nodes.data(), d.p, (n - 1) * sizeof(GuideNode), hipMemcpyDeviceToHost);
+    }
+    free_buf(d);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        return ctx->fail_hip(why, e);
+    }
+    const int rc = verify_guide_tree(nodes, boxes, n, n_nodes, max_depth);
+    if (rc != PT_OK) return ctx->fail(rc, "pt_selftest_guide_tree_device: the device-built tree breaks an invariant");
     return PT_OK;
 }
 

@@ -3,7 +3,7 @@ set -e
 cd /root/repo/rust_pathtracer_amd
 name=$1; flags=$2
 d=build/var_$name; rm -rf $d; mkdir -p $d
-for f in raygen trace shade path resolve ptgpu; do
+for f in raygen trace shade path resolve guide_build ptgpu; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $flags -c csrc/device/$f.hip -o $d/$f.o &
 done
 wait

@@ -295,3 +295,69 @@ def test_busy_times_are_unions_of_launch_intervals(pt):
         assert st.rays > 0 and st.ms_trace == 0 and st.ms_busy_all == 0 and st.ms_total > 0
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------- the guide tree built on the device
+def test_device_guide_tree_builder(gpu_ctx, pt):
+    """guide_build.hip (Morton sort + Karras hierarchy + bottom-up refit), verified on the host with the same invariants as the
+    host builder's test: every box a leaf exactly once, inside every box stored above it -- scattered boxes, flat ones, hundreds
+    of identical ones (equal Morton keys), a long thin row, huge next to tiny, two, a million."""
+    rng = np.random.default_rng(4)
+
+    def boxes(lo, size):
+        return np.concatenate([lo, lo + size], axis=1)
+
+    n = 5000
+    cases = {
+        "scattered": boxes(rng.uniform(-100, 100, (n, 3)), rng.uniform(0.01, 5, (n, 3))),
+        "flat": boxes(rng.uniform(-10, 10, (n, 3)), rng.uniform(0, 2, (n, 3)) * (rng.integers(0, 3, (n, 1)) != np.arange(3))),
+        "identical": np.tile([[1.0, 2.0, 3.0, 1.5, 2.5, 3.5]], (777, 1)),
+        "row": boxes(np.stack([np.arange(n) * 1.0, np.zeros(n), np.zeros(n)], axis=1), np.full((n, 3), 0.5)),
+        "scales": boxes(rng.uniform(-1, 1, (n, 3)) * 10.0 ** rng.integers(-6, 6, (n, 1)), 10.0 ** rng.uniform(-8, 5, (n, 3))),
+        "two": np.array([[0, 0, 0, 1, 1, 1], [0, 0, 0, 1, 1, 1.0]]),
+        "three": np.array([[0, 0, 0, 1, 1, 1], [5, 0, 0, 6, 1, 1.0], [0, 7, 0, 1, 8, 1.0]]),
+        "million": boxes(rng.uniform(-300, 300, (1_000_000, 3)), rng.uniform(0.1, 1.0, (1_000_000, 3))),
+    }
+    for name, b in cases.items():
+        nodes, depth = gpu_ctx.selftest_guide_tree_device(b)
+        assert nodes == len(b) - 1, name
+        assert depth <= 97, (name, depth)  # 64 key bits + 32 position bits
+    assert gpu_ctx.selftest_guide_tree_device(cases["scattered"])[1] <= 40
+    for bad in (np.array([[0, 0, 0, 1, 1, np.inf], [0, 0, 0, 1, 1, 1.0]]), np.array([[0, 0, 0, 1, 1, 1.0]]),
+                np.array([[0, 0, 0, 1, 1, 1.0], [2, 0, 0, 1, 1, 1.0]])):
+        with pytest.raises(pt.PtError):
+            gpu_ctx.selftest_guide_tree_device(bad)
+
+
+@pytest.mark.parametrize("world", ["SphereField", "mesh", "random"])
+def test_device_built_guide_tree_gives_identical_results(pt, oracle, world):
+    """Which builder made the guide tree must not show in any result: hits equal the oracle's bit for bit, and a render's
+    accumulation buffer equals the host-built tree's bit for bit."""
+    w, h, spp, depth, bg = 64, 36, 4, 20, (1, 1, 1)
+    if world == "SphereField":
+        s, o = su.named_pair("SphereField", 1, 1, 1, image=(w, h, spp, depth, bg))
+        cam = s.camera(0.3)
+    elif world == "mesh":
+        s, o = su.model_pair(120, 61, 1.3, (0.0, 1.5, 0.0), image=(w, h, spp, depth, bg))
+        cam = s.camera(0.0)
+    else:
+        s, o = su.random_world(31, n_objects=120, with_mesh=True)
+        cam = api.camera_new((13.0, 6.0, 9.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, w / h, 0.0, 10.0)
+    ro, rd = su.camera_rays(cam.as_array(), w, h, 40000, 3)
+    p2, d2 = su.bounce_rays(o, ro, rd, 4)
+    ro, rd = np.concatenate([ro, p2]), np.concatenate([rd, d2])
+    prim, t, normal, front = o.trace(ro, rd)
+    ctx = pt.Context(0)
+    try:
+        ctx.set_option("trace_mode", 3)
+        out = {}
+        for build in (0, 1):
+            ctx.set_option("guide_build", build)
+            ctx.upload(s)
+            assert_hits_equal(ctx.trace_batch(ro, rd), prim, t, normal, front)
+            ctx.accum_reset(w, h)
+            st = ctx.render_accumulate(cam, w, h, bg, 0, spp, depth, 9)
+            out[build] = (st.rays, ctx.accum_download())
+        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    finally:
+        ctx.close()
