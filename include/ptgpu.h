@@ -177,6 +177,9 @@ const char* pt_last_error(const PtContext* ctx);
  * "guide_build" (who builds the ordered walk's guide tree at the next pt_scene_upload: 0 = the host, binned surface-area splits
  *   (0.45 s for a million triangles; the default: its trees take ~25 % fewer steps per ray); 1 = the device, linear BVH
  *   (milliseconds: for worlds rebuilt every frame); results are identical either way),
+ * "guide_split" (guide tree, at the next pt_scene_upload: a triangle whose box is more than this many times its own projected areas is
+ *   referenced once per PIECE, cut by axis-aligned planes, at most 32 pieces and n_prims / 2 extra references per scene -- the
+ *   slivers around the pole of a latitude-longitude mesh; default 4, 0 = never; results are identical),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 
@@ -256,6 +259,10 @@ int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uin
 /* The same check of the DEVICE builder ("guide_build" 1: Morton sort + Karras hierarchy + bottom-up refit on ctx's GPU): the
  * tree is built on the device, copied back and verified on the host. */
 int pt_selftest_guide_tree_device(PtContext* ctx, const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth);
+/* Host-only: the pieces by which the guide tree references one triangle (corners: 3 x xyz; option "guide_split" = ratio): cut by
+ * axis-aligned planes until a piece's box is at most `ratio` times the piece's own projected areas (at most 32 pieces).  Writes
+ * up to `capacity` unpadded boxes (lo.xyz, hi.xyz) to `boxes` (may be null) and the number of pieces to *n_pieces. */
+int pt_selftest_split_triangle(const double corners[9], int ratio, double* boxes, size_t capacity, size_t* n_pieces);
 
 #ifdef __cplusplus
 }

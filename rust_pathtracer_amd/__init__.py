@@ -25,6 +25,7 @@ from .api import (  # noqa: F401
     camera_new,
     write_png,
     selftest_guide_tree,
+    selftest_split_triangle,
     device_count,
     libptgpu,
     libpthost,

@@ -191,6 +191,7 @@ _PTGPU_PROTOS = {
     "pt_selftest_texture": (C.c_int, [_vp, C.c_uint32, _vp, C.c_size_t, _vp]),
     "pt_selftest_guide_tree": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "pt_selftest_guide_tree_device": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "pt_selftest_split_triangle": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 _PTHOST_PROTOS = {
     "pth_last_error": (C.c_char_p, []),
@@ -270,6 +271,17 @@ def selftest_guide_tree(boxes: np.ndarray):
     if rc != 0:
         raise PtError(f"pt_selftest_guide_tree: status {rc}")
     return n_nodes.value, depth.value
+
+
+def selftest_split_triangle(corners: np.ndarray, ratio: int = 4) -> np.ndarray:
+    """The boxes [k, 6] (lo.xyz, hi.xyz, unpadded) of the pieces by which the guide tree references the triangle `corners` [3, 3]."""
+    c = np.ascontiguousarray(corners, dtype=np.float64).reshape(9)
+    out = np.zeros((64, 6), dtype=np.float64)
+    n = C.c_size_t()
+    rc = libptgpu.pt_selftest_split_triangle(c.ctypes.data, ratio, out.ctypes.data, out.shape[0], C.byref(n))
+    if rc != 0:
+        raise PtError(f"pt_selftest_split_triangle: status {rc}")
+    return out[: n.value].copy()
 
 
 def write_png(path: str, rgb: np.ndarray):

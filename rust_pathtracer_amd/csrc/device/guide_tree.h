@@ -66,6 +66,81 @@ inline float round_up(double v) {
     return ((double)f < v) ? std::nextafterf(f, INFINITY) : f;
 }
 
+// ---- Split references for thin diagonal triangles.
+// A long thin triangle that runs diagonally through space has a box hundreds of times larger than itself; where many of
+// them meet (the pole of a latitude-longitude mesh: a thousand slivers sharing a vertex) a ray near that place passes
+// through hundreds of boxes and runs as many triangle tests -- and such a ray is the slowest of its launch.  The guide
+// tree may reference a primitive more than once, each time with the box of a PIECE of it: the triangle is cut by
+// axis-aligned planes (the longest side of the piece's box, at its middle) until a piece's box is no larger than
+// `ratio` times the piece's own projected areas, or `max_depth` cuts.  The pieces cover the triangle (cut points are
+// computed in f64, rounding 1e-16 relative, against a padding of 1e-5 of the triangle's largest coordinate), so the
+// premise of the ordered walk stands: a test that reports a hit at t is crossed inside one of the primitive's padded
+// boxes at t.  The walk meets such a primitive several times; pt_device.h OrderedWalk::consider ignores the repeats.
+struct SplitPoly { double p[12][3]; int n; };
+inline double poly_half_area_ideal(const SplitPoly& q) { // |Nx| + |Ny| + |Nz|, N = sum p_i x p_(i+1) (twice the area vector)
+    double nx = 0, ny = 0, nz = 0;
+    for (int i = 0; i < q.n; ++i) {
+        const double* a = q.p[i];
+        const double* b = q.p[(i + 1) % q.n];
+        // relative to vertex 0: the sum is translation-invariant, the rounding is not
+        const double ax = a[0] - q.p[0][0], ay = a[1] - q.p[0][1], az = a[2] - q.p[0][2];
+        const double bx = b[0] - q.p[0][0], by = b[1] - q.p[0][1], bz = b[2] - q.p[0][2];
+        nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
+    }
+    return std::fabs(nx) + std::fabs(ny) + std::fabs(nz);
+}
+inline void clip_poly(const SplitPoly& in, int axis, double plane, bool keep_below, SplitPoly& out) { // Sutherland-Hodgman, one plane
+    out.n = 0;
+    for (int i = 0; i < in.n; ++i) {
+        const double* a = in.p[i];
+        const double* b = in.p[(i + 1) % in.n];
+        const bool ia = keep_below ? a[axis] <= plane : a[axis] >= plane, ib = keep_below ? b[axis] <= plane : b[axis] >= plane;
+        if (ia && out.n < 12) { for (int k = 0; k < 3; ++k) out.p[out.n][k] = a[k]; out.n += 1; }
+        if (ia != ib && out.n < 12) {
+            const double s = (plane - a[axis]) / (b[axis] - a[axis]);
+            for (int k = 0; k < 3; ++k) out.p[out.n][k] = a[k] + (b[k] - a[k]) * s;
+            out.p[out.n][axis] = plane;
+            out.n += 1;
+        }
+    }
+}
+// Appends the boxes (unpadded) of the pieces of `poly` to `out` (6 doubles each: lo.xyz, hi.xyz); returns how many.
+inline size_t split_pieces(const SplitPoly& poly, double ratio, int max_depth, std::vector<double>* out) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = 0; i < poly.n; ++i)
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], poly.p[i][k]); hi[k] = std::max(hi[k], poly.p[i][k]); }
+    const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    const double half = x * y + y * z + z * x;
+    int axis = 0;
+    if (y > x) axis = 1;
+    if (z > (axis ? y : x)) axis = 2;
+    const double mid = 0.5 * (lo[axis] + hi[axis]);
+    const bool cut = max_depth > 0 && poly.n >= 3 && poly.n <= 10 && std::isfinite(half) && half > ratio * poly_half_area_ideal(poly) &&
+                     lo[axis] < mid && mid < hi[axis];
+    if (!cut) {
+        if (out) { out->insert(out->end(), lo, lo + 3); out->insert(out->end(), hi, hi + 3); }
+        return 1;
+    }
+    SplitPoly below, above;
+    clip_poly(poly, axis, mid, true, below);
+    clip_poly(poly, axis, mid, false, above);
+    size_t n = 0;
+    if (below.n >= 3) n += split_pieces(below, ratio, max_depth - 1, out);
+    if (above.n >= 3) n += split_pieces(above, ratio, max_depth - 1, out);
+    if (n == 0) { // (cannot happen: a cut through the inside of the box leaves both sides a polygon) keep the whole
+        if (out) { out->insert(out->end(), lo, lo + 3); out->insert(out->end(), hi, hi + 3); }
+        return 1;
+    }
+    return n;
+}
+inline SplitPoly split_poly_of(const double corners[9]) {
+    SplitPoly q;
+    q.n = 3;
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) q.p[i][k] = corners[3 * i + k];
+    return q;
+}
+
 // Whether a tree can be built over these leaves at all (by either builder): at least two, every box finite with lo <= hi and
 // within what survives the rounding to f32, every stream offset within 31 bits.
 inline bool usable(const std::vector<GuideLeaf>& leaves) {

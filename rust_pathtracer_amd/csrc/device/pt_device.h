@@ -1004,6 +1004,8 @@ struct OrderedWalk {
         if (!hit) return;
         if (t != t) { // cannot happen for an ordinary ray (see begin); if it does, the literal walk decides
             q[4].y = -__builtin_huge_valf();
+        } else if ((int32_t)prim == w.best_prim) {
+            // the best primitive again, through another of its pieces' boxes (guide_tree.h split_pieces): same test, same t
         } else if (t < w.best_t || w.best_prim < 0) {
             if (w.best_prim >= 0) q[4].y = __builtin_fminf(q[4].y, f32_not_above(w.best_t) - PT_GUIDE_ABS_SLACK);
             w.best_t = t; w.best_prim = (int32_t)prim; best_parent = link;
@@ -1086,7 +1088,7 @@ struct OrderedWalk {
         if (w.off >= sc.stream_bytes) mode = PT_OW_IDLE;
     }
     __device__ __forceinline__ double result_t() const {
-#ifdef PT_DEBUG_STEPS
+#if defined(PT_DEBUG_STEPS) && !defined(PT_DEBUG_SLOW)
         return (double)steps_guide + 1e3 * (double)steps_leaf + 1e6 * (double)steps_verify + 1e9 * (double)(w.steps_nodes + w.steps_leaves) + 1e14 * (double)went_literal;
 #else
         return w.best_t;

@@ -69,6 +69,12 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
         } else {
             if (w.mode >= PT_OW_LITERAL) w.step_literal(sc, stack, B); // rare: one step per round keeps the kernel small
         }
+#ifdef PT_DEBUG_SLOW /* with PT_DEBUG_STEPS: name the rays that take more than PT_DEBUG_SLOW steps */
+        if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE &&
+            w.steps_guide + w.steps_leaf + w.steps_verify + w.w.steps_nodes + w.w.steps_leaves > PT_DEBUG_SLOW)
+            printf("slow ray: guide %u leaf %u verify %u literal %u + %u (went %u) n %u o %.17g %.17g %.17g d %.17g %.17g %.17g t %.17g prim %d\n", w.steps_guide, w.steps_leaf,
+                   w.steps_verify, w.w.steps_nodes, w.w.steps_leaves, w.went_literal, n, w.w.o.x, w.w.o.y, w.w.o.z, w.w.d.x, w.w.d.y, w.w.d.z, w.w.best_t, w.w.best_prim);
+#endif
         if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE) io.store(mine, w.w.o, w.w.d, w.result_t(), w.w.best_prim);
     }
 }

@@ -25,6 +25,9 @@ hipError_t guide_build_on_device(hipStream_t stream, const std::vector<GuideLeaf
 #ifndef PT_TAIL_FROM_LOCKSTEP
 #define PT_TAIL_FROM_LOCKSTEP 4096u /* lockstep scenes: never, unless "tail_from" says so */
 #endif
+#ifndef PT_GUIDE_SPLIT_DEPTH
+#define PT_GUIDE_SPLIT_DEPTH 5 /* at most 32 references per triangle */
+#endif
 #ifndef PT_TAIL_MIN_PRIMS
 #define PT_TAIL_MIN_PRIMS 65536u
 #endif
@@ -83,6 +86,8 @@ struct PtContext {
     int profile = 1;
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
+    int guide_split_ratio = 4;    // guide tree: a triangle whose box exceeds this many times its own projected areas is referenced per piece; 0 = never
+    int tail_deal = 1;            // the rays that enter the per-wave tail launch are first dealt out evenly over the waves
     int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
     unsigned char* scratch_ptr = nullptr; // this device's address of `scratch` (hipGetSymbolAddress at context creation)
     int guide_build_device = 0;   // 1: the ordered walk's guide tree is built on the device (guide_build.hip) instead of on the host
@@ -379,6 +384,12 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
         ctx->repack_first = (int)value;
     } else if (k == "fused") {  // 1: the whole bounce loop in one launch where the lockstep walk applies; 0: a trace and a shade launch per bounce
         ctx->fused = value ? 1 : 0;
+    } else if (k == "guide_split") {  // guide tree: split references for thin diagonal triangles (guide_tree.h); 0 off, else the area ratio that triggers a cut
+        if (value < 0 || value > 1000000) return ctx->fail(PT_ERR_BAD_ARG, "guide_split out of range [0, 1000000]");
+        ctx->guide_split_ratio = (int)value;
+    } else if (k == "tail_deal") {
+        if (value < 0 || value > 1) return ctx->fail(PT_ERR_BAD_ARG, "tail_deal must be 0 or 1");
+        ctx->tail_deal = (int)value;
     } else if (k == "tail_from") {  // ordered walk: bounces from this one on run in one per-wave launch (path.hip); -1 automatic
         if (value < -1 || value > 4096) return ctx->fail(PT_ERR_BAD_ARG, "tail_from out of range [-1, 4096]");
         ctx->tail_from = (int)value;
@@ -565,14 +576,36 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     double ow_origin_limit = 1e18, ow_tri_ratio = 0.0, ow_tri_extent = 0.0, ow_rect_m = INFINITY, ow_rect_extent = 0.0;
     double ow_leaf_m_min = INFINITY, ow_leaf_m_max = 0.0;
     {
-        auto leaf_box = [&](const double* lo, const double* hi) {
+        // (corners: a triangle's three points -- a thin diagonal one is referenced once per piece, guide_tree.h split_pieces; every
+        // piece is padded like the whole, by 1e-5 of the TRIANGLE's largest coordinate)
+        std::vector<double> pieces;
+        const size_t split_budget = want_guide && ctx->guide_split_ratio > 0 ? (size_t)s->n_prims / 2u + 4096u : 0u;
+        size_t split_extra = 0;
+        auto leaf_box = [&](const double* lo, const double* hi, const double* corners = nullptr) {
             GuideLeaf l;
             for (int q = 0; q < 3; ++q) { l.lo[q] = lo[q]; l.hi[q] = hi[q]; }
             l.offset = (uint32_t)std::min<size_t>(walk.size() * 8u, 0xFFFFFFFFu);
             guide::pad(l);
-            guide_leaves.push_back(l);
             double m = 0.0;
             for (int q = 0; q < 3; ++q) m = std::max(m, std::max(std::fabs(lo[q]), std::fabs(hi[q])));
+            pieces.clear();
+            size_t n_pieces = 1;
+            if (corners && split_extra < split_budget && std::isfinite(m))
+                n_pieces = guide::split_pieces(guide::split_poly_of(corners), (double)ctx->guide_split_ratio, PT_GUIDE_SPLIT_DEPTH, &pieces);
+            if (n_pieces > 1) {
+                const double eps = 1e-5 * m + 1e-30; // guide::pad's
+                for (size_t i = 0; i < n_pieces; ++i) {
+                    GuideLeaf piece = l;
+                    for (int q = 0; q < 3; ++q) { // (never beyond the whole triangle's padded box)
+                        piece.lo[q] = std::max(l.lo[q], pieces[6 * i + q] - eps);
+                        piece.hi[q] = std::min(l.hi[q], pieces[6 * i + 3 + q] + eps);
+                    }
+                    guide_leaves.push_back(piece);
+                }
+                split_extra += n_pieces - 1;
+            } else {
+                guide_leaves.push_back(l);
+            }
             ow_leaf_m_min = std::min(ow_leaf_m_min, m);
             ow_leaf_m_max = std::max(ow_leaf_m_max, m);
             return m; // the leaf's largest coordinate: what its padding is proportional to
@@ -641,7 +674,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
                             lo[aa] = pr.d[1]; hi[aa] = pr.d[2];
                             lo[ba] = pr.d[3]; hi[ba] = pr.d[4];
                         }
-                        const double m = leaf_box(lo, hi);
+                        const double m = leaf_box(lo, hi, pr.type == PT_PRIM_TRIANGLE ? s->prims[first + k].d : nullptr);
                         if (pr.type == PT_PRIM_SPHERE) {
                             const double c = std::max(std::fabs(pr.d[0]), std::max(std::fabs(pr.d[1]), std::fabs(pr.d[2])));
                             ow_origin_limit = std::min(ow_origin_limit, 5e4 * std::fabs(pr.d[3]) - c);
@@ -953,7 +986,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
 
     // Event bookkeeping.  Every launch is bracketed by two events on its own stream; the stop event doubles as the
     // hand-off the other lane waits on.
-    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5, K_PATH = 6, K_TAIL = 7 };
+    enum { K_RAYGEN = 0, K_TRACE = 1, K_SHADE = 2, K_FOLD = 3, K_TOTALS = 4, K_REPACK = 5, K_PATH = 6, K_TAIL = 7, K_DEAL = 8 };
     // one launch for the whole bounce loop (path.hip) where the wave-uniform walk applies and textures are solid
     const bool fused = ctx->fused && ctx->sc.trace_mode == PT_TRACE_LOCKSTEP && !ctx->sc.has_procedural && ctx->repack_every == 0;
     // ordered walk: the first few bounces as a trace and a shade launch each, the thinned-out rest in one per-wave launch.
@@ -1001,6 +1034,13 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         const uint32_t* counts_in = wf.counts;
         for (uint32_t b = 0; b < max_bounces; ++b) {
             if (b == tail_from) {
+                if (!lockstep_tail_ok && ctx->tail_deal && b > 0) {
+                    // the survivors are dealt out over the waves one at a time first (shade.hip repack_kernel<true>)
+                    BounceIO rp{buf, buf ^ 1, counts_in, wf.counts_repacked + count_row(wf, b)};
+                    pl.steps.push_back({K_DEAL, b, rp});
+                    buf ^= 1;
+                    counts_in = rp.counts_out;
+                }
                 pl.steps.push_back({lockstep_tail_ok ? K_PATH : K_TAIL, b, BounceIO{buf, buf ^ 1, counts_in, nullptr}});
                 break;
             }
@@ -1081,6 +1121,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_TRACE: launch_trace(ln.stream, geom, ctx->sc, ln.wf, st.io); ++launches_trace; break;
                     case K_SHADE: launch_shade(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_shade; break;
                     case K_REPACK: launch_repack(ln.stream, geom, ln.wf, st.io); break;
+                    case K_DEAL: launch_repack(ln.stream, geom, ln.wf, st.io, true); break;
                     case K_FOLD: launch_fold(ln.stream, plan[l].p, ln.wf, plan[l].slots, ctx->d_accum); break;
                     default: launch_count_totals(ln.stream, ln.wf, max_bounces); break;
                 }
@@ -1154,7 +1195,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_TRACE: stats->ms_trace += ms; spans[0].emplace_back(t0, t1); break;
                     case K_SHADE: stats->ms_shade += ms; spans[1].emplace_back(t0, t1); break;
                     case K_FOLD: stats->ms_fold += ms; break;
-                    case K_REPACK: stats->ms_repack += ms; break;
+                    case K_REPACK: case K_DEAL: stats->ms_repack += ms; break;
                     case K_PATH: stats->ms_path += ms; spans[2].emplace_back(t0, t1); break;
                     case K_TAIL: stats->ms_path += ms; spans[2].emplace_back(t0, t1); break;
                     default: break;
@@ -1476,6 +1517,16 @@ int pt_selftest_guide_tree(const double* boxes, size_t n, uint32_t* n_nodes, uin
     std::vector<GuideNode> nodes;
     if (!guide::build(leaves, nodes)) return PT_ERR_BAD_ARG;
     return verify_guide_tree(nodes, boxes, n, n_nodes, max_depth);
+}
+// The pieces a triangle is referenced by in the guide tree (guide_tree.h split_pieces): their unpadded boxes, 6 doubles each.
+int pt_selftest_split_triangle(const double corners[9], int ratio, double* boxes, size_t capacity, size_t* n_pieces) {
+    if (!corners || !n_pieces || ratio < 1) return PT_ERR_BAD_ARG;
+    for (int k = 0; k < 9; ++k)
+        if (!std::isfinite(corners[k])) return PT_ERR_BAD_ARG;
+    std::vector<double> out;
+    *n_pieces = guide::split_pieces(guide::split_poly_of(corners), (double)ratio, PT_GUIDE_SPLIT_DEPTH, &out);
+    if (boxes) std::memcpy(boxes, out.data(), std::min(capacity, *n_pieces) * 6 * sizeof(double));
+    return PT_OK;
 }
 int pt_selftest_guide_tree_device(PtContext* ctx, const double* boxes, size_t n, uint32_t* n_nodes, uint32_t* max_depth) {
     if (!ctx) return PT_ERR_BAD_ARG;

@@ -120,6 +120,10 @@ void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
 // n_waves counts itself -- 32 KB from L2, no inter-block hand-off), each wave copies its rays to the contiguous
 // position prefix + k, and the new layout is read off that contiguous stream: region' = max(64, ceil(total /
 // n_waves) rounded up to 64), wave w' owning [w' * region', ...).  Copies 64 B per live ray.
+// DEAL: the survivors are dealt out one at a time instead -- ray j of the contiguous order goes to wave j mod n_waves -- before
+// the per-wave tail of the bounce loop (path.hip): the long-lived paths of a frame sit in a few places of the image (the gap under
+// the mesh), so in a few waves, and a tail wave's cost per bounce is that of its slowest ray.
+template <bool DEAL>
 __global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const uint4* __restrict__ st_in, RayStream out,
                                                           uint4* __restrict__ st_out, const uint32_t* __restrict__ counts_in,
                                                           uint32_t* __restrict__ counts_out, uint32_t n_waves) {
@@ -145,23 +149,30 @@ __global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const ui
     for (uint32_t w = my_part * per; w < wave; ++w) prefix += counts_in[w];
     const uint32_t n = counts_in[wave];
     const size_t src_base = (size_t)wave * counts_in[n_waves];
+    uint32_t region = ((total + n_waves - 1) / n_waves + 63u) & ~63u;
+    if (region < 64u) region = 64u;
     for (uint32_t k = lane; k < n; k += 64u) {
-        const size_t src = src_base + k, dst = (size_t)prefix + k;
+        const size_t src = src_base + k;
+        const uint32_t j = prefix + k;
+        const size_t dst = DEAL ? (size_t)(j % n_waves) * region + j / n_waves : (size_t)j;
         out.a[dst] = in.a[src];
         out.b[dst] = in.b[src];
         out.c[dst] = in.c[src];
         st_out[dst] = st_in[src];
     }
-    uint32_t region = ((total + n_waves - 1) / n_waves + 63u) & ~63u;
-    if (region < 64u) region = 64u;
     if (lane == 0) {
         const unsigned long long start = (unsigned long long)wave * region;
-        counts_out[wave] = start >= total ? 0u : (total - start < region ? (uint32_t)(total - start) : region);
+        if (DEAL) counts_out[wave] = total / n_waves + (wave < total % n_waves ? 1u : 0u);
+        else counts_out[wave] = start >= total ? 0u : (total - start < region ? (uint32_t)(total - start) : region);
     }
     if (wave == 0 && lane == 0) counts_out[n_waves] = region;
 }
 
-void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io) {
-    hipLaunchKernelGGL(repack_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, wf.rays[io.in], wf.state[io.in], wf.rays[io.out],
-                       wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves);
+void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io, bool deal) {
+    if (deal)
+        hipLaunchKernelGGL(repack_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), 0, s, wf.rays[io.in], wf.state[io.in], wf.rays[io.out],
+                           wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves);
+    else
+        hipLaunchKernelGGL(repack_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), 0, s, wf.rays[io.in], wf.state[io.in], wf.rays[io.out],
+                           wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves);
 }

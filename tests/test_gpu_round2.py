@@ -361,3 +361,43 @@ def test_device_built_guide_tree_gives_identical_results(pt, oracle, world):
         assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
     finally:
         ctx.close()
+
+
+def test_split_references_and_dealt_tail_do_not_change_results(pt, oracle):
+    """guide_split references a thin diagonal triangle once per piece (the slivers around a mesh's poles) and tail_deal
+    re-deals the rays before the per-wave tail: hits stay bit-equal to the oracle's -- also for rays aimed at the poles,
+    where a ray meets the same triangle through several boxes -- and the accumulation buffer does not change by a bit."""
+    w, h, spp, depth, bg = 64, 36, 4, 20, (1, 1, 1)
+    s, o = su.model_pair(120, 61, 1.3, (0.0, 1.5, 0.0), image=(w, h, spp, depth, bg))
+    cam = s.camera(0.0)
+    ro, rd = su.camera_rays(cam.as_array(), w, h, 20000, 3)
+    p2, d2 = su.bounce_rays(o, ro, rd, 4)
+    rng = np.random.default_rng(5)
+    # at the two poles of the mesh: x = z = center, from above / below / the side, through points within a sliver's length
+    r_top, r_bottom = 1.3 * (1.0 + 0.07), 1.3 * (1.0 - 0.07)  # scene.cpp make_synthetic_mesh: radius * (1 + 0.07 cos(9 theta)) on the axis
+    poles = np.array([[0.0, 1.5 + r_top, 0.0], [0.0, 1.5 - r_bottom, 0.0]])
+    n = 6000
+    target = poles[rng.integers(0, 2, n)] + rng.normal(size=(n, 3)) * np.array([0.02, 0.002, 0.02])
+    origin = target + rng.normal(size=(n, 3)) * np.array([1.0, 0.3, 1.0]) + np.array([0.0, 0.0, 0.0])
+    ro = np.concatenate([ro, p2, origin])
+    rd = np.concatenate([rd, d2, target - origin])
+    prim, t, normal, front = o.trace(ro, rd)
+    assert (prim[-n:] >= 0).mean() > 0.3  # the pole rays do hit the mesh
+    ctx = pt.Context(0)
+    try:
+        ctx.set_option("trace_mode", 3)
+        ctx.set_option("tail_from", 2)
+        out = []
+        for split, deal, build in ((0, 0, 0), (4, 1, 0), (1, 1, 0), (4, 0, 1), (1000, 1, 0)):
+            ctx.set_option("guide_split", split)
+            ctx.set_option("tail_deal", deal)
+            ctx.set_option("guide_build", build)
+            ctx.upload(s)
+            assert_hits_equal(ctx.trace_batch(ro, rd), prim, t, normal, front)
+            ctx.accum_reset(w, h)
+            st = ctx.render_accumulate(cam, w, h, bg, 0, spp, depth, 9)
+            out.append((st.rays, ctx.accum_download()))
+        for rays, img in out[1:]:
+            assert rays == out[0][0] and np.array_equal(img, out[0][1])
+    finally:
+        ctx.close()

@@ -360,3 +360,38 @@ def test_host_layer_is_clean_under_sanitizers():
     r = subprocess.run(["make", "-C", pkg, "asan"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "all checks passed" in r.stdout
+
+
+def test_triangle_split_pieces_cover_the_triangle(pt):
+    """guide_tree.h split_pieces (option "guide_split"): the boxes of the pieces cover every point of the triangle, a
+    compact triangle stays whole, a diagonal sliver is cut into boxes far smaller than its own."""
+    rng = np.random.default_rng(11)
+
+    def covered(tri, ratio):
+        b = pt.selftest_split_triangle(tri, ratio)
+        wgt = rng.random((4000, 3)) ** 2
+        wgt /= wgt.sum(1, keepdims=True)
+        pts = np.concatenate([wgt @ tri, tri, 0.5 * (tri + np.roll(tri, 1, 0))])
+        scale = np.abs(tri).max() * 1e-12
+        inside = ((pts[:, None, :] >= b[None, :, :3] - scale) & (pts[:, None, :] <= b[None, :, 3:] + scale)).all(2).any(1)
+        lo, hi = tri.min(0), tri.max(0)
+        assert (b[:, :3] >= lo - scale).all() and (b[:, 3:] <= hi + scale).all()  # no piece sticks out of the triangle's box
+        return len(b), bool(inside.all())
+
+    assert covered(np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0]]), 4) == (1, True)  # axis-aligned, compact: one reference
+    sliver = np.array([[0.0, 10.5, 0.0], [0.62, 10.51, 0.62], [0.6161, 10.51, 0.6239]])
+    n, ok = covered(sliver, 4)
+    assert ok and 8 <= n <= 32
+    b = pt.selftest_split_triangle(sliver, 4)
+    area = lambda q: (q[:, 3] - q[:, 0]) * (q[:, 5] - q[:, 2])
+    assert area(b).sum() < 0.1 * 0.62 * 0.6239  # the pieces' footprints against the whole box's
+    for k in range(300):
+        tri = rng.normal(size=(3, 3)) * 10 ** rng.uniform(-3, 3) + rng.normal(size=3) * 10 ** rng.uniform(-2, 4)
+        if k % 3 == 0:
+            tri[2] = tri[1] + (tri[1] - tri[0]) * 0.01 + rng.normal(size=3) * 1e-3 * np.abs(tri).max()
+        if k % 7 == 0:
+            tri[2] = tri[0] + (tri[1] - tri[0]) * 0.5  # degenerate: three points on a line
+        n, ok = covered(tri, int(rng.integers(1, 9)))
+        assert ok and 1 <= n <= 32, (tri, n)
+    with pytest.raises(pt.PtError):
+        pt.selftest_split_triangle(np.array([[0.0, 0, 0], [1, 0, np.nan], [0, 1, 0]]), 4)
