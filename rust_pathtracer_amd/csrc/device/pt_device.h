@@ -963,13 +963,20 @@ struct OrderedWalk {
         "v_pk_fma_f32 %0, %0, %3, %4 op_sel:[0," #sel_inv "," #sel_nr "] op_sel_hi:[1," #sel_inv "," #sel_nr "]"                       \
         : "=&v"(out)                                                                                                                 \
         : "v"(planes), "v"(c_of), "v"(c_inv), "v"(c_nr))
+    static __device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     __device__ __forceinline__ bool guide_slab(pt_f32x2 x, pt_f32x2 y, pt_f32x2 z, float bound, float tmin_dn, float& entry) const {
         pt_f32x2 tx, ty, tz;
         PT_PK_SLAB(tx, x, q[0], 0, q[1], 1, q[3], 0);
         PT_PK_SLAB(ty, y, q[0], 1, q[2], 0, q[3], 1);
         PT_PK_SLAB(tz, z, q[1], 0, q[2], 1, q[4], 0);
-        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fminf(tz.x, tz.y));
-        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
+        // (min / max as instructions as well: behind fminf / fmaxf the compiler first quiets a possible signalling NaN in each input
+        // that comes out of an asm statement -- six extra instructions per box for values that are never NaN)
+        const float nx = raw_min(tx.x, tx.y), ny = raw_min(ty.x, ty.y), nz = raw_min(tz.x, tz.y);
+        const float fx = raw_max(tx.x, tx.y), fy = raw_max(ty.x, ty.y), fz = raw_max(tz.x, tz.y);
+        float tn, tf;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx), "v"(ny), "v"(nz));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(fz));
         tn = __builtin_fmaf(__builtin_fabsf(tn), -5e-7f, tn);
         tf = __builtin_fmaf(__builtin_fabsf(tf), 5e-7f, tf);
         entry = tn;

@@ -24,6 +24,19 @@
 #ifndef PT_ORD_VERIFY_LANES
 #define PT_ORD_VERIFY_LANES 12
 #endif
+#ifdef PT_DEBUG_PHASES /* debugging aid: rounds and active lanes per kind of step, summed over all waves (read with pt_debug_read_phases) */
+__device__ unsigned long long pt_debug_phase[16];
+#define PT_PHASE_COUNT(slot, active_mask)                                                                   \
+    do {                                                                                                    \
+        const unsigned long long mask_ = (active_mask); /* (the ballot: all lanes take part) */             \
+        if ((threadIdx.x & 63u) == 0u) {                                                                    \
+            atomicAdd(&pt_debug_phase[2 * (slot)], 1ull);                                                   \
+            atomicAdd(&pt_debug_phase[2 * (slot) + 1], (unsigned long long)__builtin_popcountll(mask_));   \
+        }                                                                                                   \
+    } while (0)
+#else
+#define PT_PHASE_COUNT(slot, active_mask) do {} while (0)
+#endif
 template <class RayIo>
 __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
     uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
@@ -41,6 +54,7 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
         if (next < n && n_idle >= PT_ORD_REFILL_LANES) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t k = next + rank;
+            PT_PHASE_COUNT(0, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE && k < n));
             if (w.mode == PT_OW_IDLE && k < n) {
                 mine = k;
                 V3 o, d;
@@ -59,14 +73,19 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
         const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
         const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode >= PT_OW_LITERAL));
         if (n_verify >= PT_ORD_VERIFY_LANES || (n_verify != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u)) {
+            PT_PHASE_COUNT(1, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_VERIFY));
             if (w.mode == PT_OW_VERIFY) w.step_verify(sc, stack, B);
         } else if (n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) {
 #pragma unroll
-            for (int r = 0; r < PT_ORD_NODE_STEPS; ++r)
+            for (int r = 0; r < PT_ORD_NODE_STEPS; ++r) {
+                PT_PHASE_COUNT(2 + r, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE));
                 if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack, B);
+            }
         } else if (n_leaf != 0u && n_leaf >= n_literal) {
+            PT_PHASE_COUNT(6, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
             if (w.mode == PT_OW_LEAF) w.step_leaf(sc, stack, B);
         } else {
+            PT_PHASE_COUNT(7, __builtin_amdgcn_ballot_w64(w.mode >= PT_OW_LITERAL));
             if (w.mode >= PT_OW_LITERAL) w.step_literal(sc, stack, B); // rare: one step per round keeps the kernel small
         }
 #ifdef PT_DEBUG_SLOW /* with PT_DEBUG_STEPS: name the rays that take more than PT_DEBUG_SLOW steps */

@@ -315,3 +315,14 @@ void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, 
         hipLaunchKernelGGL(trace_batch_kernel<false>, dim3(blocks), dim3(PT_BLOCK), g.trace_lds_bytes, s, sc, origins, dirs, n,
                            t_min, t_max, out);
 }
+
+#ifdef PT_DEBUG_PHASES
+extern "C" int pt_debug_read_phases(unsigned long long* out, int reset) { // 8 x (rounds, active lanes): refill, verify, guide step 0..3, leaf, literal
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_debug_phase), sizeof(pt_debug_phase)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pt_debug_phase), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
