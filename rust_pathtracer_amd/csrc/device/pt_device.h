@@ -818,6 +818,9 @@ struct OrderedScene { // wave-uniform: what the ordered walk reads
 __host__ __device__ inline OrderedScene ordered_scene(const DevScene& sc) {
     return OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes, sc.ow_origin_limit, sc.ow_tri_extent, sc.ow_od_limit};
 }
+#ifdef PT_DEBUG_PHASES /* debugging aid (pt_ordered.h): counters summed over all waves, read with pt_debug_read_phases */
+__device__ unsigned long long pt_debug_phase[32];
+#endif
 typedef float pt_f32x2 __attribute__((ext_vector_type(2)));
 // What is the same for every ray of a kernel (wave-uniform: it lives in scalar registers, not once per lane).
 struct OrderedBounds {
@@ -999,6 +1002,18 @@ struct OrderedWalk {
         const bool h1 = guide_slab(pair_of(w.g[3]), pair_of(w.g[4]), pair_of(w.g[5]), bound, B.tmin_dn, e1);
         const uint32_t c0 = w.kind, c1 = w.aux;
         const bool both = h0 && h1, swap = both && e1 < e0;
+#if defined(PT_DEBUG_PHASES) && !defined(PT_DEBUG_PHASES_TIME_ONLY)
+        {
+            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(!h0 && !h1), m2 = __builtin_amdgcn_ballot_w64(both);
+            const unsigned long long mh = __builtin_amdgcn_ballot_w64(w.best_prim >= 0), mh0 = __builtin_amdgcn_ballot_w64(w.best_prim >= 0 && !h0 && !h1);
+            if ((threadIdx.x & 63u) == 0u) {
+                atomicAdd(&pt_debug_phase[16], (unsigned long long)__builtin_popcountll(m0));
+                atomicAdd(&pt_debug_phase[17], (unsigned long long)__builtin_popcountll(m2));
+                atomicAdd(&pt_debug_phase[18], (unsigned long long)__builtin_popcountll(mh));
+                atomicAdd(&pt_debug_phase[19], (unsigned long long)__builtin_popcountll(mh0));
+            }
+        }
+#endif
         const bool overflow = both && sp >= PT_GUIDE_STACK;
         if (both && !overflow) {
             stack[sp * PT_BLOCK] = swap ? c0 : c1;

@@ -25,7 +25,9 @@
 #define PT_ORD_VERIFY_LANES 12
 #endif
 #ifdef PT_DEBUG_PHASES /* debugging aid: rounds and active lanes per kind of step, summed over all waves (read with pt_debug_read_phases) */
-__device__ unsigned long long pt_debug_phase[16];
+#ifdef PT_DEBUG_PHASES_TIME_ONLY /* (the counters' atomics would be most of what the clocks see) */
+#define PT_PHASE_COUNT(slot, active_mask) do {} while (0)
+#else
 #define PT_PHASE_COUNT(slot, active_mask)                                                                   \
     do {                                                                                                    \
         const unsigned long long mask_ = (active_mask); /* (the ballot: all lanes take part) */             \
@@ -34,8 +36,30 @@ __device__ unsigned long long pt_debug_phase[16];
             atomicAdd(&pt_debug_phase[2 * (slot) + 1], (unsigned long long)__builtin_popcountll(mask_));   \
         }                                                                                                   \
     } while (0)
+#endif
+#define PT_PHASE_CLOCK(var) const unsigned long long var = __builtin_readcyclecounter()
+#define PT_PHASE_TIME(slot, from, to)                                                                      \
+    do { /* summed per wave in registers, one atomic per part when the wave is done (PT_PHASE_FLUSH) */    \
+        const unsigned long long d_ = (to) - (from);                                                       \
+        const int s_ = (slot);                                                                             \
+        pt0 += s_ == 0 ? d_ : 0ull; pt1 += s_ == 1 ? d_ : 0ull; pt2 += s_ == 2 ? d_ : 0ull; pt3 += s_ == 3 ? d_ : 0ull; \
+        pt4 += s_ == 4 ? d_ : 0ull; pt5 += s_ == 5 ? d_ : 0ull; pt6 += s_ == 6 ? d_ : 0ull;               \
+    } while (0)
+#define PT_PHASE_DECL unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0, pt5 = 0, pt6 = 0
+#define PT_PHASE_FLUSH                                                                                     \
+    do {                                                                                                   \
+        if ((threadIdx.x & 63u) == 0u) {                                                                   \
+            atomicAdd(&pt_debug_phase[24], pt0); atomicAdd(&pt_debug_phase[25], pt1); atomicAdd(&pt_debug_phase[26], pt2); \
+            atomicAdd(&pt_debug_phase[27], pt3); atomicAdd(&pt_debug_phase[28], pt4); atomicAdd(&pt_debug_phase[29], pt5); \
+            atomicAdd(&pt_debug_phase[30], pt6);                                                           \
+        }                                                                                                  \
+    } while (0)
 #else
 #define PT_PHASE_COUNT(slot, active_mask) do {} while (0)
+#define PT_PHASE_CLOCK(var) do {} while (0)
+#define PT_PHASE_TIME(slot, from, to) do {} while (0)
+#define PT_PHASE_DECL do {} while (0)
+#define PT_PHASE_FLUSH do {} while (0)
 #endif
 template <class RayIo>
 __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
@@ -48,7 +72,9 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
 #endif
     w.begin(sc, stack, B, v3(0, 0, 0), v3(1, 1, 1));
     w.mode = PT_OW_IDLE;
+    PT_PHASE_DECL;
     for (;;) {
+        PT_PHASE_CLOCK(c_top);
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
         if (next < n && n_idle >= PT_ORD_REFILL_LANES) {
@@ -65,6 +91,8 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
         } else if (n_idle == 64u) {
             break;
         }
+        PT_PHASE_CLOCK(c_refilled);
+        PT_PHASE_TIME(0, c_top, c_refilled);
         const uint32_t mode_before = w.mode;
         // One kind of step per round: guide-tree box tests, the proof step (it forms the ray's three reciprocals: run when
         // enough lanes have gathered for it, or nothing else is left to do), primitive tests, or the literal walk.
@@ -72,6 +100,11 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
         const uint32_t n_verify = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_VERIFY));
         const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
         const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode >= PT_OW_LITERAL));
+        PT_PHASE_CLOCK(c_chosen);
+        PT_PHASE_TIME(5, c_refilled, c_chosen);
+        const int phase_slot = (n_verify >= PT_ORD_VERIFY_LANES || (n_verify != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u)) ? 1
+                               : (n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) ? 2 : (n_leaf != 0u && n_leaf >= n_literal) ? 3 : 4;
+        (void)phase_slot;
         if (n_verify >= PT_ORD_VERIFY_LANES || (n_verify != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u)) {
             PT_PHASE_COUNT(1, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_VERIFY));
             if (w.mode == PT_OW_VERIFY) w.step_verify(sc, stack, B);
@@ -94,8 +127,13 @@ __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32
             printf("slow ray: guide %u leaf %u verify %u literal %u + %u (went %u) n %u o %.17g %.17g %.17g d %.17g %.17g %.17g t %.17g prim %d\n", w.steps_guide, w.steps_leaf,
                    w.steps_verify, w.w.steps_nodes, w.w.steps_leaves, w.went_literal, n, w.w.o.x, w.w.o.y, w.w.o.z, w.w.d.x, w.w.d.y, w.w.d.z, w.w.best_t, w.w.best_prim);
 #endif
+        PT_PHASE_CLOCK(c_stepped);
+        PT_PHASE_TIME(phase_slot, c_chosen, c_stepped);
         if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE) io.store(mine, w.w.o, w.w.d, w.result_t(), w.w.best_prim);
+        PT_PHASE_CLOCK(c_stored);
+        PT_PHASE_TIME(6, c_stepped, c_stored);
     }
+    PT_PHASE_FLUSH;
 }
 
 struct RegionRayIo { // the wave's region of the wavefront ray stream

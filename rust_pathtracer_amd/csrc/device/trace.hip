@@ -317,10 +317,10 @@ void launch_trace_batch(hipStream_t s, const LaunchGeom& g, const DevScene& sc, 
 }
 
 #ifdef PT_DEBUG_PHASES
-extern "C" int pt_debug_read_phases(unsigned long long* out, int reset) { // 8 x (rounds, active lanes): refill, verify, guide step 0..3, leaf, literal
+extern "C" int pt_debug_read_phases(unsigned long long* out, int reset) { // 8 x (rounds, active lanes): refill, verify, guide step 0..3, leaf, literal; then guide steps with no child hit, with both hit, taken with a hit in hand, both
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_debug_phase), sizeof(pt_debug_phase)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long zero[16] = {0};
+        unsigned long long zero[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(pt_debug_phase), zero, sizeof(zero)) != hipSuccess) return -1;
     }
     return 0;

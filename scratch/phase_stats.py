@@ -18,7 +18,7 @@ for a in sys.argv[2:]:
 ctx.upload(s)
 cam = s.camera(0.0)
 w, h = 1920, 1080
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 api.libptgpu.pt_debug_read_phases(out, 1)
 ctx.accum_reset(w, h)
 st = ctx.render_accumulate(cam, w, h, (1, 1, 1), 0, spp, 50, 1)
@@ -29,3 +29,8 @@ print(f"{which}: rays {st.rays}, ms {st.ms_total:.1f}")
 for i, nm in enumerate(names):
     r, l = out[2 * i], out[2 * i + 1]
     print(f"  {nm:8s} rounds {r:12d}  mean active lanes {l / max(r, 1):6.2f}  lane-steps per ray {l / st.rays:6.2f}")
+g = max(1, sum(out[2 * i + 1] for i in range(2, 6)))
+print(f"  guide lane-steps {g}: no child hit {out[16] / g:.3f}, both hit {out[17] / g:.3f}; taken with a hit in hand {out[18] / g:.3f}, of those with no child hit {out[19] / max(out[18], 1):.3f}")
+tnames = ["refill", "verify", "guide", "leaf", "literal", "choose", "store"]
+tot = sum(out[24 + i] for i in range(7))
+print("  wave-time by part of the loop: " + ", ".join(f"{nm} {out[24 + i] / tot:.3f}" for i, nm in enumerate(tnames)) + f"  (total {tot / 1e9:.2f} G wave-cycles)")
