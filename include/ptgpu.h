@@ -177,6 +177,9 @@ const char* pt_last_error(const PtContext* ctx);
  * "guide_build" (who builds the ordered walk's guide tree at the next pt_scene_upload: 0 = the host, binned surface-area splits
  *   (0.45 s for a million triangles; the default: its trees take ~25 % fewer steps per ray); 1 = the device, linear BVH
  *   (milliseconds: for worlds rebuilt every frame); results are identical either way),
+ * "tail_deal" (1, the default: the rays that enter that one launch are first dealt out over the waves one at a time -- the long-lived
+ *   paths of a frame sit in a few image tiles, so in a few waves, and a tail wave's cost per bounce is that of its slowest ray; 0 = each
+ *   wave keeps its own) and "tail_waves_div" (dealt over 1 / this many of the waves; default 1),
  * "guide_split" (guide tree, at the next pt_scene_upload: a triangle whose box is more than this many times its own projected areas is
  *   referenced once per PIECE, cut by axis-aligned planes, at most 32 pieces and n_prims / 2 extra references per scene -- the
  *   slivers around the pole of a latitude-longitude mesh; default 4, 0 = never; results are identical),

@@ -64,7 +64,7 @@ void launch_tail(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const P
 struct ShadeEnv;
 ShadeEnv make_shade_env(const PassParams& p, const Wavefront& wf, uint32_t bounce);
 // Re-deals the rays of buffer io.in evenly over the waves into buffer io.out (counts_in -> counts_out).
-void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io, bool deal = false);
+void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io, uint32_t deal_waves = 0); // deal_waves > 0: dealt out one by one over that many waves
 void launch_fold(hipStream_t s, const PassParams& p, const Wavefront& wf, uint32_t sample_slots, float* accum);
 void launch_count_totals(hipStream_t s, const Wavefront& wf, uint32_t n_bounces);
 void launch_resolve(hipStream_t s, const float* accum, uint32_t n_values, uint32_t total_spp, uint8_t* rgb);

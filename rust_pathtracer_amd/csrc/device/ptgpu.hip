@@ -87,6 +87,7 @@ struct PtContext {
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
     int guide_split_ratio = 4;    // guide tree: a triangle whose box exceeds this many times its own projected areas is referenced per piece; 0 = never
+    int tail_waves_div = 1;       // ... over n_waves / this many of them
     int tail_deal = 1;            // the rays that enter the per-wave tail launch are first dealt out evenly over the waves
     int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
     unsigned char* scratch_ptr = nullptr; // this device's address of `scratch` (hipGetSymbolAddress at context creation)
@@ -387,6 +388,9 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
     } else if (k == "guide_split") {  // guide tree: split references for thin diagonal triangles (guide_tree.h); 0 off, else the area ratio that triggers a cut
         if (value < 0 || value > 1000000) return ctx->fail(PT_ERR_BAD_ARG, "guide_split out of range [0, 1000000]");
         ctx->guide_split_ratio = (int)value;
+    } else if (k == "tail_waves_div") {
+        if (value < 1 || value > 64) return ctx->fail(PT_ERR_BAD_ARG, "tail_waves_div out of range [1, 64]");
+        ctx->tail_waves_div = (int)value;
     } else if (k == "tail_deal") {
         if (value < 0 || value > 1) return ctx->fail(PT_ERR_BAD_ARG, "tail_deal must be 0 or 1");
         ctx->tail_deal = (int)value;
@@ -1121,7 +1125,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
                     case K_TRACE: launch_trace(ln.stream, geom, ctx->sc, ln.wf, st.io); ++launches_trace; break;
                     case K_SHADE: launch_shade(ln.stream, geom, ctx->sc, plan[l].p, ln.wf, st.io, st.bounce); ++launches_shade; break;
                     case K_REPACK: launch_repack(ln.stream, geom, ln.wf, st.io); break;
-                    case K_DEAL: launch_repack(ln.stream, geom, ln.wf, st.io, true); break;
+                    case K_DEAL: launch_repack(ln.stream, geom, ln.wf, st.io, std::max<uint32_t>(1u, ln.wf.n_waves / (uint32_t)ctx->tail_waves_div)); break;
                     case K_FOLD: launch_fold(ln.stream, plan[l].p, ln.wf, plan[l].slots, ctx->d_accum); break;
                     default: launch_count_totals(ln.stream, ln.wf, max_bounces); break;
                 }

@@ -126,7 +126,7 @@ void launch_shade(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const 
 template <bool DEAL>
 __global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const uint4* __restrict__ st_in, RayStream out,
                                                           uint4* __restrict__ st_out, const uint32_t* __restrict__ counts_in,
-                                                          uint32_t* __restrict__ counts_out, uint32_t n_waves) {
+                                                          uint32_t* __restrict__ counts_out, uint32_t n_waves, uint32_t deal_waves) {
     __shared__ uint32_t s_part[PT_BLOCK];
     const uint32_t per = (n_waves + PT_BLOCK - 1) / PT_BLOCK;
     uint32_t acc = 0;
@@ -149,12 +149,15 @@ __global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const ui
     for (uint32_t w = my_part * per; w < wave; ++w) prefix += counts_in[w];
     const uint32_t n = counts_in[wave];
     const size_t src_base = (size_t)wave * counts_in[n_waves];
-    uint32_t region = ((total + n_waves - 1) / n_waves + 63u) & ~63u;
+    // (DEAL: over the first deal_waves waves only -- late in the tail a wave holds a handful of rays and pays a whole wave's
+    // instructions for them; fewer, fuller waves pay them less often)
+    const uint32_t targets = DEAL ? deal_waves : n_waves;
+    uint32_t region = ((total + targets - 1) / targets + 63u) & ~63u;
     if (region < 64u) region = 64u;
     for (uint32_t k = lane; k < n; k += 64u) {
         const size_t src = src_base + k;
         const uint32_t j = prefix + k;
-        const size_t dst = DEAL ? (size_t)(j % n_waves) * region + j / n_waves : (size_t)j;
+        const size_t dst = DEAL ? (size_t)(j % targets) * region + j / targets : (size_t)j;
         out.a[dst] = in.a[src];
         out.b[dst] = in.b[src];
         out.c[dst] = in.c[src];
@@ -162,17 +165,17 @@ __global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const ui
     }
     if (lane == 0) {
         const unsigned long long start = (unsigned long long)wave * region;
-        if (DEAL) counts_out[wave] = total / n_waves + (wave < total % n_waves ? 1u : 0u);
+        if (DEAL) counts_out[wave] = wave < targets ? total / targets + (wave < total % targets ? 1u : 0u) : 0u;
         else counts_out[wave] = start >= total ? 0u : (total - start < region ? (uint32_t)(total - start) : region);
     }
     if (wave == 0 && lane == 0) counts_out[n_waves] = region;
 }
 
-void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io, bool deal) {
-    if (deal)
+void launch_repack(hipStream_t s, const LaunchGeom& g, const Wavefront& wf, const BounceIO& io, uint32_t deal_waves) {
+    if (deal_waves)
         hipLaunchKernelGGL(repack_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), 0, s, wf.rays[io.in], wf.state[io.in], wf.rays[io.out],
-                           wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves);
+                           wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves, std::min(deal_waves, wf.n_waves));
     else
         hipLaunchKernelGGL(repack_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), 0, s, wf.rays[io.in], wf.state[io.in], wf.rays[io.out],
-                           wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves);
+                           wf.state[io.out], io.counts_in, io.counts_out, wf.n_waves, wf.n_waves);
 }

@@ -391,6 +391,7 @@ def test_split_references_and_dealt_tail_do_not_change_results(pt, oracle):
         for split, deal, build in ((0, 0, 0), (4, 1, 0), (1, 1, 0), (4, 0, 1), (1000, 1, 0)):
             ctx.set_option("guide_split", split)
             ctx.set_option("tail_deal", deal)
+            ctx.set_option("tail_waves_div", 4 if split == 1 else 1)  # (dealt over a quarter of the waves, once)
             ctx.set_option("guide_build", build)
             ctx.upload(s)
             assert_hits_equal(ctx.trace_batch(ro, rd), prim, t, normal, front)
