@@ -41,4 +41,4 @@ else:
         # (prim < 0 => t is reported as 0: misses carry no counts)
         okk = hit["prim"] >= 0
         def q(x): return "mean %.1f p50 %.0f p90 %.0f p99 %.0f max %.0f" % (x.mean(), *np.percentile(x, [50, 90, 99]), x.max())
-        print(f"bounce {b}: {okk.sum()} hits of {len(okk)}; guide steps: {q(guide[okk])}; leaf: {q(leaf[okk])}; verify {q(ver[okk])}; literal rays {int(lit[okk].sum())}, literal steps {q(litsteps[okk])}", flush=True)
+        print(f"[{' '.join(sys.argv[2:]) or 'defaults'}] bounce {b}: {okk.sum()} hits of {len(okk)}; guide steps: {q(guide[okk])}; leaf: {q(leaf[okk])}; verify {q(ver[okk])}; literal rays {int(lit[okk].sum())}, literal steps {q(litsteps[okk])}", flush=True)
