@@ -1,6 +1,6 @@
-# usage (GPU box): bash scratch/sf_probe.sh   -- SphereField frames (config 5, 8 frames) under tail_from / tail_deal settings
+# usage (GPU box): bash scratch/sf_probe.sh "<bench options>" ...   -- SphereField frames (config 5, 8 frames) under sets of bench.py options
 set -e
-for o in "" "--opt tail_from=4" "--opt tail_from=8" "--opt tail_from=12" "--opt tail_from=20" "--opt tail_from=8 --opt tail_deal=0"; do
+for o in "$@"; do
   echo "== $o"
   timeout -k 10 200 python -u bench.py --config 5 --frames 8 --steps 1 --warmup 1 --no-cpu-baseline $o 2>/dev/null | python -c "
 import json,sys
