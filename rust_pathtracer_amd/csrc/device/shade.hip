@@ -151,9 +151,17 @@ __global__ __launch_bounds__(PT_BLOCK) void repack_kernel(RayStream in, const ui
     const size_t src_base = (size_t)wave * counts_in[n_waves];
     // (DEAL: over the first deal_waves waves only -- late in the tail a wave holds a handful of rays and pays a whole wave's
     // instructions for them; fewer, fuller waves pay them less often)
-    const uint32_t targets = DEAL ? deal_waves : n_waves;
+    uint32_t targets = DEAL ? deal_waves : n_waves;
     uint32_t region = ((total + targets - 1) / targets + 63u) & ~63u;
     if (region < 64u) region = 64u;
+    // (fewer target waves mean larger regions, rounded up to 64 each: when nearly every path is still alive that can exceed
+    // what the streams hold -- n_waves regions of the current size -- and the deal then goes over all the waves, which always fits:
+    // round64(ceil(total / n_waves)) never exceeds the region size the pass started with)
+    if (DEAL && (unsigned long long)targets * region > (unsigned long long)n_waves * counts_in[n_waves]) {
+        targets = n_waves;
+        region = ((total + targets - 1) / targets + 63u) & ~63u;
+        if (region < 64u) region = 64u;
+    }
     for (uint32_t k = lane; k < n; k += 64u) {
         const size_t src = src_base + k;
         const uint32_t j = prefix + k;

@@ -402,3 +402,29 @@ def test_split_references_and_dealt_tail_do_not_change_results(pt, oracle):
             assert rays == out[0][0] and np.array_equal(img, out[0][1])
     finally:
         ctx.close()
+
+
+def test_dealt_tail_with_fewer_waves_never_overruns_its_regions(pt):
+    """tail_waves_div deals the tail's rays over fewer waves, i.e. into larger regions: in a closed box, where nearly every path
+    is still alive at bounce 1, the regions of a third / a seventh / a 64th of the waves would not fit the streams, and the
+    kernel must fall back to all waves.  Same accumulation buffer as without the deal, bit for bit."""
+    w, h, spp, depth, bg = 96, 64, 8, 12, (0, 0, 0)
+    s = pt.Scene("CornellBox").set_seeds(1, 1, 1).set_image(w, h, spp, depth, bg).build()
+    cam = s.camera(0.0)
+    ctx = pt.Context(0)
+    try:
+        ctx.set_option("trace_mode", 3)
+        ctx.set_option("tail_from", 1)
+        ctx.upload(s)
+        out = []
+        for deal, div in ((0, 1), (1, 1), (1, 2), (1, 3), (1, 7), (1, 64)):
+            ctx.set_option("tail_deal", deal)
+            ctx.set_option("tail_waves_div", div)
+            ctx.accum_reset(w, h)
+            st = ctx.render_accumulate(cam, w, h, bg, 0, spp, depth, 3)
+            out.append((st.rays, ctx.accum_download()))
+        assert out[0][0] > w * h * spp * 3  # paths do live on
+        for rays, img in out[1:]:
+            assert rays == out[0][0] and np.array_equal(img, out[0][1])
+    finally:
+        ctx.close()
