@@ -176,7 +176,7 @@ const char* pt_last_error(const PtContext* ctx);
  *   per 32-spp frame for never / 16 / 12); results are identical),
  * "guide_build" (who builds the ordered walk's guide tree at the next pt_scene_upload: 0 = the host, binned surface-area splits
  *   (0.45 s for a million triangles; the default: its trees take ~12 % fewer steps per ray); 1 = the device, linear BVH
- *   (tens of milliseconds for a million triangles: for worlds rebuilt every frame); results are identical either way),
+ *   (7 ms of kernels for a million triangles: for worlds rebuilt every frame); results are identical either way),
  * "tail_deal" (1, the default: the rays that enter that one launch are first dealt out over the waves one at a time -- the long-lived
  *   paths of a frame sit in a few image tiles, so in a few waves, and a tail wave's cost per bounce is that of its slowest ray; 0 = each
  *   wave keeps its own) and "tail_waves_div" (dealt over 1 / this many of the waves; default 1),
