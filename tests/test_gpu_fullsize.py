@@ -70,6 +70,30 @@ def test_config3_million_triangles(gpu_ctx, oracle, pt):
     want, rays = o.render_accumulate(cam.as_array(), w, h, (1, 1, 1), 0, 2, depth, 3)
     assert st.rays == rays
     _close(gpu_ctx.accum_download().astype(np.float64), want)
+    # At BASELINE.json's full image size (1920x1080), where the oracle would take minutes: what must not depend on how the frame
+    # is scheduled -- the tail's deal, split references in the guide tree, who built the tree -- does not: same ray count per
+    # bounce and the same accumulation buffer bit for bit; and the two halves of the sample range sum to the whole.
+    W, H = 1920, 1080
+    ctx = pt.Context(0)
+    try:
+        out = []
+        for split, deal, build in ((4, 1, 0), (0, 0, 0), (4, 1, 1)):
+            ctx.set_option("guide_split", split)
+            ctx.set_option("tail_deal", deal)
+            ctx.set_option("guide_build", build)
+            ctx.upload(s)
+            ctx.accum_reset(W, H)
+            st = ctx.render_accumulate(cam, W, H, (1, 1, 1), 0, 2, depth, 3)
+            out.append(([int(v) for v in st.rays_per_bounce[:50]], ctx.accum_download()))
+        for per_bounce, img in out[1:]:
+            assert per_bounce == out[0][0] and np.array_equal(img, out[0][1])
+        assert out[0][0][0] == W * H * 2 and out[0][0][49] > 0  # every primary ray is a segment; some paths live all 50 bounces
+        ctx.accum_reset(W, H)
+        ra = ctx.render_accumulate(cam, W, H, (1, 1, 1), 0, 1, depth, 3).rays
+        rb = ctx.render_accumulate(cam, W, H, (1, 1, 1), 1, 1, depth, 3).rays
+        assert ra + rb == sum(out[0][0]) and np.allclose(ctx.accum_download(), out[0][1], rtol=1e-5, atol=1e-5)
+    finally:
+        ctx.close()
 
 
 def test_config4_lighttest_4k_sample_sharding(gpu_ctx, oracle):
