@@ -137,7 +137,7 @@ def cpu_baseline(cfg, seed, target_seconds, rays_per_frame, product_scene=None):
     single-thread rate on a third of that time, and the frame time both extrapolate to."""
     import oracle_api as orc
 
-    threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU
+    threads = min(16, os.cpu_count() or 1)  # the GPU box's CPU share for one GPU (the box caps worker pools at 16)
     w, h = 480, 270
     sc, custom = oracle_scene_for(cfg, product_scene)
     if custom:
@@ -167,6 +167,7 @@ def cpu_baseline(cfg, seed, target_seconds, rays_per_frame, product_scene=None):
         "value": round(mrays, 3),
         "unit": "Mrays/s",
         "cores": threads,
+        "cores_available": os.cpu_count(),
         "kind": "port",
         "sample": f"{cfg['scene']} {w}x{h}, {spp} spp, depth {depth}: {rays} rays in {dt:.2f} s "
                   f"(C++ restatement of rust-pathtracer, not the Rust binary)",
@@ -202,7 +203,7 @@ def run_config1(args, cfg):
         "data": f"synthetic (scene.rs {cfg['scene']} constants, seeded BVH and Perlin table)",
         "config": {"workload": cfg["label"], "parallelism": f"CPU, {threads} threads", "rays_per_frame": int(rays), "image": out},
         "roofline": None,
-        "cpu_baseline": {"value": round(mrays, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "cpu_baseline": {"value": round(mrays, 3), "unit": "Mrays/s", "cores": threads, "cores_available": os.cpu_count(), "kind": "port",
                          "sample": f"the whole configuration: {rays} rays in {dt:.2f} s (C++ restatement of rust-pathtracer, not the Rust binary)"},
     }
     print(json.dumps(line))
@@ -279,34 +280,44 @@ class Worker:
 
 
 def sum_stats(stats_list):
+    """Sums the PtStats of several render calls.  Every call's rays are split between the kernels that traced them: bounces
+    [0, tail_from) ran as one trace and one shade launch each, bounces [tail_from, depth) inside the fused path / tail launch
+    (PtStats.tail_from; = depth when no such launch ran)."""
     keys = ("rays", "ms_total", "ms_raygen", "ms_trace", "ms_shade", "ms_fold", "ms_repack", "ms_path", "ms_busy_trace", "ms_busy_shade",
             "ms_busy_path", "ms_busy_all", "launches_trace", "launches_shade", "launches_path")
     out = {k: 0 for k in keys}
-    out["rays_bounce0"] = 0
+    out.update(rays_wavefront=0, survivors_wavefront=0, rays_tail=0, survivors_tail=0, tail_from=None)
     for st in stats_list:
         for k in keys:
             out[k] += getattr(st, k)
-        out["rays_bounce0"] += st.rays_per_bounce[0]
+        rpb = [int(x) for x in st.rays_per_bounce]
+        tf = min(int(st.tail_from), len(rpb) - 1)  # (bounces >= 63 are folded into the last slot: with depth <= 63 nothing is)
+        out["rays_wavefront"] += sum(rpb[:tf])                # rays entering the separate trace + shade launches
+        out["survivors_wavefront"] += sum(rpb[1:tf + 1])      # what their shade launches wrote: the rays entering bounces 1..tail_from
+        out["rays_tail"] += sum(rpb[tf:])                     # rays entering a bounce inside the tail launch
+        out["survivors_tail"] += sum(rpb[tf + 1:])            # what the tail launch wrote back between its bounces
+        out["tail_from"] = tf if out["tail_from"] is None else min(out["tail_from"], tf)
     return out
 
 
 def kernel_entries(tot, pmc, rays_per_s_whole, n_cus, clock_hz):
-    """Per-kernel roofline entries from the summed PtStats of the timed region (rank / GPU 0)."""
-    rays, survivors = tot["rays"], tot["rays"] - tot["rays_bounce0"]  # rays entering bounces >= 1 are shade's survivors
-    table = [("trace_kernel", tot["ms_trace"], tot["ms_busy_trace"], tot["launches_trace"], rays * BYTES_TRACE),
-             ("shade_kernel", tot["ms_shade"], tot["ms_busy_shade"], tot["launches_shade"], rays * BYTES_SHADE_IN + survivors * BYTES_SHADE_OUT)]
-    if tot["ms_path"] > 0:  # fused / tail launches cover some of the bounces: their rays are not split out, so the byte figure is an upper bound
-        table.append(("path_kernel", tot["ms_path"], tot["ms_busy_path"], tot["launches_path"], None))
+    """Per-kernel roofline entries from the summed PtStats of the timed region (rank / GPU 0): algorithmic bytes of the rays each
+    kernel really processed over the sum of its launch durations."""
+    rw, sw, rt, stl = tot["rays_wavefront"], tot["survivors_wavefront"], tot["rays_tail"], tot["survivors_tail"]
+    table = [("trace_kernel", tot["ms_trace"], tot["ms_busy_trace"], tot["launches_trace"], rw * BYTES_TRACE, rw),
+             ("shade_kernel", tot["ms_shade"], tot["ms_busy_shade"], tot["launches_shade"], rw * BYTES_SHADE_IN + sw * BYTES_SHADE_OUT, rw),
+             # fused path / tail launch: per ray entering one of its bounces 64 B in (ray 48 + state 16; the hit record stays in
+             # registers), per survivor 64 B out
+             ("path_kernel", tot["ms_path"], tot["ms_busy_path"], tot["launches_path"], rt * BYTES_PATH_IN + stl * BYTES_SHADE_OUT, rt)]
     out = []
-    for name, ms_sum, ms_busy, launches, nbytes in table:
+    for name, ms_sum, ms_busy, launches, nbytes, rays in table:
         if launches == 0 or ms_sum <= 0:
             continue
-        e = {"kernel": name, "launches": launches, "launch_ms_sum": round(ms_sum, 3), "busy_ms": round(ms_busy, 3),
-             "avg_launch_ms": round(ms_sum / launches, 5)}
-        if nbytes is not None:
-            achieved = nbytes / (ms_sum * 1e-3) / 1e9
-            e.update({"bytes_per_launch": int(nbytes / launches), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5),
-                      "achieved_while_busy": round(nbytes / (ms_busy * 1e-3) / 1e9, 2) if ms_busy > 0 else None})
+        achieved = nbytes / (ms_sum * 1e-3) / 1e9
+        e = {"kernel": name, "launches": launches, "rays": int(rays), "launch_ms_sum": round(ms_sum, 3), "busy_ms": round(ms_busy, 3),
+             "avg_launch_ms": round(ms_sum / launches, 5), "bytes_per_launch": int(nbytes / launches), "achieved": round(achieved, 2),
+             "frac": round(achieved / HBM_PEAK_GBS, 5),
+             "achieved_while_busy": round(nbytes / (ms_busy * 1e-3) / 1e9, 2) if ms_busy > 0 else None}
         p = pmc.get(name)
         if p and p.get("hbm_bytes_per_ray") is not None:
             e["traffic"] = int(p["hbm_bytes_per_ray"] * rays / launches)
@@ -359,6 +370,7 @@ def main():
     import torch
 
     import rust_pathtracer_amd as pt
+    from rust_pathtracer_amd.distributed import render_static_sharded
 
     dist = None
     if per_process:
@@ -401,11 +413,11 @@ def main():
             return
         if per_process:
             accum.zero_()  # (the bound tensor is the accumulation buffer; accum_reset would clear the internal one)
+            torch.cuda.synchronize()
             root.stats = []
-            begin, count = pt.sample_range_for_rank(spp, rank, world)
-            if count:
-                root.render_samples(begin, count)
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI, on torch's stream
+            # this rank's sample range, then ONE reduce to rank 0 (RCCL over xGMI, on torch's stream): the function that
+            # tests/test_distributed_cpu.py runs over gloo
+            render_static_sharded(root.render_samples, accum, spp, rank, world, dist)
             torch.cuda.synchronize()
         else:
             everyone("static_share")
@@ -495,6 +507,7 @@ def main():
                         "avg_launch_ms": with_bytes["avg_launch_ms"], "bytes_per_launch": with_bytes["bytes_per_launch"],
                         "dominant_by": "largest sum of launch durations in the timed region (GPU 0)",
                         "profiled_steps": profiled_steps,
+                        "tail_from": tot["tail_from"],  # bounces before it: trace_kernel + shade_kernel; from it on: path_kernel
                         "kernels": kernels,
                         "pipeline_frac": round(mrays * 1e6 * BYTES_SEGMENT / world / (HBM_PEAK_GBS * 1e9), 5)}
             if iso is not None:
@@ -541,8 +554,10 @@ def main():
                                                    if cfg.get("rebuild") else "world built and uploaded once (not rebuilt)"}
         if args.out_image and root.img is not None:
             pt.write_png(args.out_image, root.img)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, args.cpu_seconds, rays_total // (args.steps * frames_per_step), root.scene)
+        if not args.no_cpu_baseline:
+            # the same host cores whatever N is: with N > 1 a shorter sample (the line must still finish within minutes)
+            seconds = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0)
+            out["cpu_baseline"] = cpu_baseline(cfg, args.seed, seconds, rays_total // (args.steps * frames_per_step), root.scene)
         print(json.dumps(out))
     for wk in workers:
         wk.close()

@@ -141,6 +141,10 @@ typedef struct PtStats {
     double ms_busy_path;
     double ms_busy_all;       /* union over every kernel of the call (<= ms_total; the rest is launch gaps) */
     uint64_t rays_per_bounce[64]; /* live rays entering bounce b (b >= 64 folded into the last slot) */
+    uint32_t tail_from;       /* bounces [0, tail_from) ran as one trace and one shade launch each, bounces [tail_from, max_bounces) inside
+                                 the fused path / tail launch (= max_bounces when no such launch ran): what splits rays_per_bounce
+                                 between the kernels */
+    uint32_t reserved_;
 } PtStats;
 
 typedef struct PtContext PtContext;
@@ -227,20 +231,22 @@ void* pt_accum_device_ptr(PtContext* ctx);
  * (width*height*3 floats: 24.9 MB at 1080p, 99.5 MB at 4K), each rank's part enqueued on that context's stream
  * inside one ncclGroupStart/End.  The other contexts' buffers are left as they were.  Returns after every stream has
  * drained; ctxs[0] can then be resolved with the TOTAL spp.  n == 1 is the identity (and still goes through RCCL).
- * The communicators (ncclCommInitAll over the contexts' devices, in the order given) are created on first use and
- * kept for the process.  librccl.so.1 is loaded on the first call, not at link time: a host that never shards needs no
+ * The communicators (ncclCommInitAll over the contexts' devices, in the order given) are created on the first call with a
+ * given list of contexts and kept until one of those contexts is destroyed (pt_context_destroy calls ncclCommDestroy).  librccl.so.1 is loaded on the first call, not at link time: a host that never shards needs no
  * RCCL.  One thread calls this for all n contexts, after the threads that drove them have returned from their calls.
  * PT_ERR_BAD_ARG: null / repeated context, two contexts on one device, sizes differ; PT_ERR_STATE: before
  * pt_accum_reset; PT_ERR_RCCL: library missing or an RCCL call failed. */
 int pt_accum_reduce(PtContext** ctxs, int n);
 
-/* pt_trace_batch for callers that cannot allocate device memory (HIP-graph capture around the call site, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same kernels and
- * bit-identical results, but the device copies of the rays and of the hit records live in a fixed scratch array inside
- * the library (a file-scope __device__ array, PT_TRACE_STATIC_MAX_RAYS * 88 bytes = 5.5 MiB held per GPU for the life of
- * the process) instead of buffers allocated and freed per call: the call makes no hipMalloc / hipFree and no other
- * allocating call.  n > PT_TRACE_STATIC_MAX_RAYS is refused with PT_ERR_BAD_ARG.  All calls on one GPU share that GPU's
- * array, whatever the context: calls that overlap in time on one GPU race; the call returns after its stream drained. */
+/* pt_trace_batch for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc, code
+ * that runs between the captures of a HIP graph and must not disturb the allocator).  No counterpart in the reference.  Same
+ * arguments, same kernels and bit-identical results, but the device copies of the rays and of the hit records live in a fixed
+ * scratch array inside the library (a file-scope __device__ array, PT_TRACE_STATIC_MAX_RAYS * 88 bytes = 5.5 MiB held per GPU
+ * for the life of the process) instead of buffers allocated and freed per call: the call makes no hipMalloc / hipFree and no
+ * other allocating call.  It is NOT itself capturable into a HIP graph: like pt_trace_batch it copies from and to pageable
+ * host memory and returns after its stream has drained.  n > PT_TRACE_STATIC_MAX_RAYS is refused with PT_ERR_BAD_ARG.  All
+ * calls on one GPU share that GPU's array, whatever the context: within one process the library serializes them (a per-GPU
+ * mutex held for the call); calls from DIFFERENT processes cannot overlap on the array (each process has its own copy). */
 #define PT_TRACE_STATIC_MAX_RAYS 65536u
 int pt_trace_batch_static(PtContext* ctx, const double* origins, const double* dirs, size_t n, double t_min, double t_max,
                           PtHitOut* out);

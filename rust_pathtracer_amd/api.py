@@ -123,6 +123,8 @@ class PtStats(C.Structure):
         ("ms_busy_path", C.c_double),
         ("ms_busy_all", C.c_double),
         ("rays_per_bounce", C.c_uint64 * 64),
+        ("tail_from", C.c_uint32),
+        ("reserved_", C.c_uint32),
     ]
 
 

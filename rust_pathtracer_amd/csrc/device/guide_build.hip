@@ -90,21 +90,19 @@ __global__ void guide_hierarchy_kernel(const uint64_t* __restrict__ keys, int n,
     if (i == 0) parent_of_node[0] = -1;
 }
 
-__device__ __forceinline__ float coherent_load(const float* p) { // written by another workgroup a moment ago: not from this CU's L1
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 __global__ void guide_refit_kernel(const DevGuideLeaf* __restrict__ leaves, const uint32_t* __restrict__ order, int n, const int2* __restrict__ kids,
-                                   const int* __restrict__ parent_of_node, const int* __restrict__ parent_of_leaf, unsigned* __restrict__ arrivals,
-                                   float* __restrict__ own_box /* lo.xyz hi.xyz per internal node */, GuideNode* __restrict__ nodes) {
+                                   const int* __restrict__ parent_of_node, const int* __restrict__ parent_of_leaf, unsigned* arrivals,
+                                   float* own_box /* lo.xyz hi.xyz per internal node; written and read across workgroups */, GuideNode* __restrict__ nodes) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     int node = parent_of_leaf[p];
     // (a tree over 64-bit keys and 32-bit positions is at most 96 levels deep: the guard makes a malformed hierarchy end the loop
     // instead of hanging the GPU; the selftest and the upload's users would then see a broken tree, never a stuck kernel)
     for (int guard = 0; node >= 0 && guard < 128; ++guard) {
-        __threadfence(); // what this thread finished below (its subtree's box) before the counter says so
-        if (atomicAdd(&arrivals[node], 1u) == 0u) return; // first to arrive: the other subtree is not finished, its thread goes on
+        // Release: what this thread finished below (its subtree's box, plain stores) is visible before the counter says so.
+        // Acquire: the second arriver sees the first one's box (plain loads below) because it saw the first one's count.
+        if (__hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            return; // first to arrive: the other subtree is not finished, its thread goes on
         const int2 k = kids[node];
         float box[2][6];
         uint32_t ref[2];
@@ -116,7 +114,7 @@ __global__ void guide_refit_kernel(const DevGuideLeaf* __restrict__ leaves, cons
                 for (int q = 0; q < 3; ++q) { box[c][q] = l.lo[q]; box[c][3 + q] = l.hi[q]; }
                 ref[c] = PT_GUIDE_LEAF | l.offset;
             } else {
-                for (int q = 0; q < 6; ++q) box[c][q] = coherent_load(own_box + (size_t)kid * 6 + q);
+                for (int q = 0; q < 6; ++q) box[c][q] = own_box[(size_t)kid * 6 + q];
                 ref[c] = (uint32_t)kid;
             }
         }
@@ -128,8 +126,8 @@ __global__ void guide_refit_kernel(const DevGuideLeaf* __restrict__ leaves, cons
             for (int q = 0; q < 3; ++q) { out.box[c][2 * q] = box[c][q]; out.box[c][2 * q + 1] = box[c][3 + q]; }
         nodes[node] = out;
         for (int q = 0; q < 3; ++q) {
-            __hip_atomic_store(own_box + (size_t)node * 6 + q, fminf(box[0][q], box[1][q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(own_box + (size_t)node * 6 + 3 + q, fmaxf(box[0][3 + q], box[1][3 + q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            own_box[(size_t)node * 6 + q] = fminf(box[0][q], box[1][q]);
+            own_box[(size_t)node * 6 + 3 + q] = fmaxf(box[0][3 + q], box[1][3 + q]);
         }
         node = parent_of_node[node];
     }
@@ -208,7 +206,15 @@ hipError_t guide_build_on_device(hipStream_t stream, const std::vector<GuideLeaf
     hipLaunchKernelGGL(guide_refit_kernel, dim3(grid_leaves), dim3(block), 0, stream, d_leaves, order_out, (int)n, kids, parent_of_node, parent_of_leaf,
                        arrivals, own_box, d_nodes);
     GB_TRY(hipGetLastError(), "guide_refit_kernel");
+    // Completion: the root is written by the second of its two subtrees to arrive.  Anything else (a malformed hierarchy that
+    // tripped the loop guard) would leave nodes unwritten in d_nodes, which is not zeroed: refuse the tree instead of uploading it.
+    unsigned root_arrivals = 0;
+    GB_TRY(hipMemcpyAsync(&root_arrivals, arrivals, sizeof(unsigned), hipMemcpyDeviceToHost, stream), "hipMemcpy(arrivals)");
     GB_TRY(hipStreamSynchronize(stream), "guide build");
 #undef GB_TRY
+    if (root_arrivals != 2u) {
+        *reason = "guide_refit_kernel: the hierarchy did not close at the root (device-built guide tree refused)";
+        return hipErrorUnknown;
+    }
     return hipSuccess;
 }

@@ -117,6 +117,9 @@ namespace {
 // Address of `scratch` on `device`, which must be the current device: looked up once per device, then remembered.
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[256] = {};
+// One call at a time per GPU may use that GPU's array (pt_trace_batch_static holds this for its whole duration): two host
+// threads driving two contexts on one GPU then take turns instead of overwriting each other's rays and hit records.
+std::mutex g_scratch_in_use[256];
 hipError_t scratch_for_device(int device, unsigned char** out) {
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     const bool cached = device >= 0 && device < 256;
@@ -132,6 +135,8 @@ hipError_t scratch_for_device(int device, unsigned char** out) {
     *out = (unsigned char*)p;
     return hipSuccess;
 }
+
+void release_cliques_of(PtContext* ctx); // below, with pt_accum_reduce: the RCCL communicators made for ctx
 
 void free_buf(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
@@ -341,6 +346,7 @@ void pt_context_destroy(PtContext* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t st : ctx->extra_streams)
         if (st) (void)hipStreamSynchronize(st);
+    release_cliques_of(ctx); // communicators of every pt_accum_reduce clique this context was part of (its stream has drained)
     for (hipEvent_t ev : ctx->events) (void)hipEventDestroy(ev);
     free_wavefront(ctx);
     free_buf(ctx->d_nodes);
@@ -891,6 +897,7 @@ int pt_trace_batch_static(PtContext* ctx, const double* origins, const double* d
     if (n == 0) return PT_OK;
     if (!origins || !dirs || !out) return ctx->fail(PT_ERR_BAD_ARG, "pt_trace_batch_static: null array");
     if (!ctx->scratch_ptr) return ctx->fail(PT_ERR_STATE, "pt_trace_batch_static: no scratch address for this device");
+    std::lock_guard<std::mutex> in_use(g_scratch_in_use[(unsigned)ctx->device & 255u]); // calls of this PROCESS on one GPU serialize
     PT_HIP(ctx, hipSetDevice(ctx->device));
     static_assert(sizeof(PtHitOut) == 40, "scratch layout assumes 40-byte hit records");
     double* d_o = reinterpret_cast<double*>(ctx->scratch_ptr);
@@ -1172,6 +1179,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         stats->launches_trace = launches_trace;
         stats->launches_shade = launches_shade;
         stats->launches_path = launches_path;
+        stats->tail_from = tail_from < max_bounces ? tail_from : max_bounces;
         for (uint32_t b = 0; b < max_bounces; ++b) {
             unsigned long long v = 0;
             for (int l = 0; l < n_lanes; ++l) v += totals[(size_t)l * n_counts + b];
@@ -1318,7 +1326,32 @@ struct Rccl {
 };
 std::mutex g_rccl_mutex;                                   // one reduce at a time per process
 Rccl g_rccl;
-std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms; // device list (rank order) -> its clique, kept for the process
+// A clique = the communicators ncclCommInitAll made for one list of contexts (rank order), kept until one of those contexts
+// is destroyed (release_cliques_of): a host that renders frame after frame on the same contexts pays for the set-up once.
+struct Clique {
+    std::vector<PtContext*> members;
+    std::vector<ncclComm_t> comms;
+};
+std::vector<Clique> g_cliques;
+
+void release_cliques_of(PtContext* ctx) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    for (size_t i = 0; i < g_cliques.size();) {
+        Clique& c = g_cliques[i];
+        if (std::find(c.members.begin(), c.members.end(), ctx) == c.members.end()) {
+            ++i;
+            continue;
+        }
+        // every member's last reduce has drained: pt_accum_reduce returns only after synchronising all their streams
+        for (size_t k = 0; k < c.comms.size(); ++k) {
+            if (!c.comms[k]) continue;
+            (void)hipSetDevice(c.members[k]->device);
+            (void)g_rccl.CommDestroy(c.comms[k]);
+        }
+        g_cliques.erase(g_cliques.begin() + (long)i);
+    }
+    (void)hipSetDevice(ctx->device);
+}
 }  // namespace
 
 extern "C" int pt_accum_reduce(PtContext** ctxs, int n) {
@@ -1354,14 +1387,18 @@ extern "C" int pt_accum_reduce(PtContext** ctxs, int n) {
     auto rccl_fail = [&](const char* what, ncclResult_t e) { return fail_all(PT_ERR_RCCL, std::string(what) + ": " + r.GetErrorString(e)); };
     auto hip_fail = [&](const char* what, hipError_t e) { return fail_all(PT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
 
-    auto it = g_comms.find(devices);
-    if (it == g_comms.end()) {
-        std::vector<ncclComm_t> comms((size_t)n, nullptr);
-        ncclResult_t e = r.CommInitAll(comms.data(), n, devices.data());
+    const std::vector<PtContext*> members(ctxs, ctxs + n);
+    const Clique* clique = nullptr;
+    for (const Clique& c : g_cliques)
+        if (c.members == members) clique = &c;
+    if (!clique) {
+        std::vector<ncclComm_t> made((size_t)n, nullptr);
+        ncclResult_t e = r.CommInitAll(made.data(), n, devices.data());
         if (e != ncclSuccess) return rccl_fail("ncclCommInitAll", e);
-        it = g_comms.emplace(devices, std::move(comms)).first;
+        g_cliques.push_back(Clique{members, std::move(made)});
+        clique = &g_cliques.back();
     }
-    const std::vector<ncclComm_t>& comms = it->second;
+    const std::vector<ncclComm_t>& comms = clique->comms;
     const size_t count = (size_t)root->width * root->height * 3;
     // every context's earlier work (its render) runs on its own stream: the reduce is ordered behind it there
     ncclResult_t e = r.GroupStart();

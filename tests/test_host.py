@@ -37,6 +37,31 @@ def test_pod_layouts_match_the_header():
     assert C.sizeof(api.PtTexture) == 48 and C.sizeof(api.PtCamera) == 152 and C.sizeof(api.PtHitOut) == 40
 
 
+def test_pod_layouts_cover_the_stats_struct():
+    # PtStats as the header declares it: 6 x 8-byte head, 11 doubles, 64 counters, tail_from + padding
+    assert C.sizeof(api.PtStats) == 8 + 8 + 4 * 4 + 11 * 8 + 64 * 8 + 8
+    assert api.PtStats.tail_from.offset == C.sizeof(api.PtStats) - 8
+
+
+def test_static_archive_links_from_plain_c():
+    """include/ptgpu.h compiles as C11 (gcc, not g++) and lib/libptgpu.a links with the line INTEGRATION.md section 1 gives a
+    build.rs (archive + amdhip64 + stdc++ + dl): `make all` builds bin/abi_check that way.  Without a GPU the program checks the
+    documented refusal and exits 77; with one it checks three hand-derived hits and a frame (tests/test_gpu_round3.py)."""
+    import subprocess
+
+    pkg = os.path.join(ROOT, "rust_pathtracer_amd")
+    exe = os.path.join(pkg, "bin", "abi_check")
+    assert os.path.exists(exe), "bin/abi_check is missing: make -C rust_pathtracer_amd all"
+    assert os.path.getmtime(exe) >= os.path.getmtime(os.path.join(pkg, "lib", "libptgpu.a")) - 1.0, "abi_check is older than the archive"
+    # the executable carries the library's code itself: it must not depend on libptgpu.so
+    needed = subprocess.run(["readelf", "-d", exe], capture_output=True, text=True, timeout=60).stdout
+    assert "libptgpu" not in needed and "libamdhip64" in needed
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode in (0, 77), r.stdout + r.stderr
+    if api.device_count() == 0:
+        assert r.returncode == 77 and "refused as documented" in r.stdout
+
+
 def test_no_gpu_fails_loudly(pt):
     if pt.device_count() > 0:
         pytest.skip("a GPU is present")
