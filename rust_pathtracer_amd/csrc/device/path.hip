@@ -139,7 +139,7 @@ void tail_kernel(DevScene sc, TailArgs a) {
     __shared__ __align__(16) unsigned char s_table[TABLE_LDS ? PT_SHADE_LDS_MAX_PRIMS * sizeof(ShadePrim) : 16];
     __shared__ __align__(16) uint8_t s_perlin[shade_lds_aux_bytes<PROCEDURAL>()];
     __shared__ uint2 s_exchange[PT_BLOCK];
-    __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
+    __shared__ uint32_t s_stack[PT_GUIDE_STACK_SLOTS * PT_BLOCK];
     const bool perlin_in_lds = shade_stage_tables<PROCEDURAL, TABLE_LDS>(sc, s_table, s_perlin);
     uint2* exchange = s_exchange + (threadIdx.x & ~63u);
     const uint32_t wave = blockIdx.x * (PT_BLOCK / PT_WAVE) + (threadIdx.x >> 6);

@@ -807,6 +807,7 @@ struct StreamWalk {
 // Correctness never rests on the guide tree being good, only on its boxes containing their primitives.
 #define PT_GUIDE_LEAF 0x80000000u
 #define PT_GUIDE_STACK 20 /* 20 KB of LDS per block: six blocks of the tail kernel (path.hip) fit a CU; deeper => literal walk */
+#define PT_GUIDE_STACK_SLOTS (PT_GUIDE_STACK + 1) /* levels the kernels allocate: one to spare for pt_lean.h's unconditional store */
 #define PT_GUIDE_ABS_SLACK 1e-37f /* see OrderedWalk::guide_slab */
 enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4, PT_OW_LITERAL_BEGIN = 5 };
 struct OrderedScene { // wave-uniform: what the ordered walk reads
@@ -814,9 +815,15 @@ struct OrderedScene { // wave-uniform: what the ordered walk reads
     const unsigned char* stream; // record stream with parent links, padded by 128 bytes
     uint32_t guide_nodes, stream_bytes;
     double origin_limit, tri_extent, od_limit; // DevScene::ow_*
+    // The guide tree's allocation also holds, right behind the nodes, a copy of the record stream (pt_scene_upload): everything
+    // the walk fetches is then `base` + a 32-bit offset (pt_lean.h).
+    const unsigned char* base;   // = guide
+    uint32_t guide_bytes;        // guide_nodes * 64: where the stream copy starts
+    uint32_t fetch_limit;        // guide_bytes + stream_bytes: the last offset a fetch may start at (128 bytes of padding follow)
 };
 __host__ __device__ inline OrderedScene ordered_scene(const DevScene& sc) {
-    return OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes, sc.ow_origin_limit, sc.ow_tri_extent, sc.ow_od_limit};
+    return OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes, sc.ow_origin_limit, sc.ow_tri_extent, sc.ow_od_limit,
+                        sc.guide, sc.guide_nodes * 64u, sc.guide_nodes * 64u + sc.walk_bytes};
 }
 #ifdef PT_DEBUG_PHASES /* debugging aid (pt_ordered.h): counters summed over all waves, read with pt_debug_read_phases */
 __device__ unsigned long long pt_debug_phase[32];

@@ -2,6 +2,12 @@
 // and the per-wave tail of the bounce loop (path.hip).
 #pragma once
 #include "pt_launch.h"
+#include "pt_lean.h"
+
+// 1: the walk of pt_lean.h (the default); 0: OrderedWalk as written in pt_device.h (kept for A/B builds, scratch/build_variant.sh)
+#ifndef PT_ORDERED_LEAN
+#define PT_ORDERED_LEAN 1
+#endif
 
 // Measured on SphereField (1080p, 32 spp): handing out rays when 40 lanes are idle, primitive tests when 16 lanes wait
 // for one, four box tests per round: 26.9 ms of trace per frame (16 / 24 / 4, the stream walk's values: 29.7 ms).
@@ -63,8 +69,96 @@
 #endif
 // UNROLL_STEPS: the box steps of a round as straight-line code (the trace kernels: SphereField 32 spp 25.6 against 26.3 ms) or as a
 // loop (the tail kernel, which also carries the shading code: fewer spilled values, 1M mesh 16 spp tail 7.8 -> 6.8 ms).
+#ifndef PT_LW_FINISH_LANES
+#define PT_LW_FINISH_LANES 12
+#endif
+// The wave loop over pt_lean.h's walk: one kind of step per round -- hand out rays, box tests (PT_ORD_NODE_STEPS in a row),
+// primitive tests, end-of-traversal decisions + proof steps, or the literal walk -- chosen from how many lanes want which.
+template <bool UNROLL_STEPS, class RayIo>
+__device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
+    uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
+    uint32_t mine = 0;
+    const OrderedBounds B = OrderedWalk::bounds(t_min, t_max);
+    LeanWalk w;
+    w.begin(sc, B, v3(0, 0, 0), v3(1, 1, 1));
+    w.mode = PT_LW_IDLE;
+    PT_PHASE_DECL;
+    for (;;) {
+        PT_PHASE_CLOCK(c_top);
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_LW_IDLE);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (next < n && n_idle >= PT_ORD_REFILL_LANES) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            const uint32_t k = next + rank;
+            PT_PHASE_COUNT(0, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_IDLE && k < n));
+            if (w.mode == PT_LW_IDLE && k < n) {
+                mine = k;
+                V3 o, d;
+                io.load(k, o, d);
+                w.begin(sc, B, o, d);
+            }
+            next = min(n, next + n_idle);
+        } else if (n_idle == 64u) {
+            break;
+        }
+        PT_PHASE_CLOCK(c_refilled);
+        PT_PHASE_TIME(0, c_top, c_refilled);
+        const uint32_t n_guide = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_LW_GUIDE));
+        const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_LW_LEAF));
+        const uint32_t n_finish = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_LW_FINISH || w.mode == PT_LW_VERIFY));
+        const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode >= PT_LW_LITERAL));
+        PT_PHASE_CLOCK(c_chosen);
+        PT_PHASE_TIME(5, c_refilled, c_chosen);
+        const bool run_finish = n_finish >= PT_LW_FINISH_LANES || (n_finish != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u);
+        const bool run_guide = !run_finish && n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES;
+        const bool run_leaf = !run_finish && !run_guide && n_leaf != 0u && n_leaf >= n_literal;
+        const int phase_slot = run_finish ? 1 : run_guide ? 2 : run_leaf ? 3 : 4;
+        (void)phase_slot;
+        bool finished = false; // this lane's ray got its answer in this round
+        if (run_finish) {
+            // lanes whose parent box has arrived take the proof step; lanes whose traversal just ended decide and fetch it
+            PT_PHASE_COUNT(1, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_FINISH || w.mode == PT_LW_VERIFY));
+            const uint32_t before = w.mode;
+            if (before == PT_LW_VERIFY) w.step_verify(B);
+            if (before == PT_LW_FINISH) w.step_finish(sc);
+            finished = w.mode == PT_LW_IDLE && (before == PT_LW_VERIFY || before == PT_LW_FINISH);
+        } else if (run_guide) {
+            if (UNROLL_STEPS) {
+#pragma unroll
+                for (int r = 0; r < PT_ORD_NODE_STEPS; ++r) {
+                    PT_PHASE_COUNT(2 + r, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_GUIDE));
+                    if (w.mode == PT_LW_GUIDE) w.step_guide(sc, stack, B);
+                }
+            } else {
+#pragma nounroll
+                for (int r = 0; r < PT_ORD_NODE_STEPS; ++r)
+                    if (w.mode == PT_LW_GUIDE) w.step_guide(sc, stack, B);
+            }
+        } else if (run_leaf) {
+            PT_PHASE_COUNT(6, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_LEAF));
+            if (w.mode == PT_LW_LEAF) w.step_leaf(sc, stack, B);
+        } else {
+            PT_PHASE_COUNT(7, __builtin_amdgcn_ballot_w64(w.mode >= PT_LW_LITERAL));
+            if (w.mode >= PT_LW_LITERAL) { // rare: one step per round keeps the kernel small
+                w.step_literal(sc, stack, B);
+                finished = w.mode == PT_LW_IDLE;
+            }
+        }
+        PT_PHASE_CLOCK(c_stepped);
+        PT_PHASE_TIME(phase_slot, c_chosen, c_stepped);
+        if (finished) io.store(mine, w.w.o, w.w.d, w.w.best_t, w.w.best_prim);
+        PT_PHASE_CLOCK(c_stored);
+        PT_PHASE_TIME(6, c_stepped, c_stored);
+    }
+    PT_PHASE_FLUSH;
+}
+
 template <bool UNROLL_STEPS = true, class RayIo>
 __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
+#if PT_ORDERED_LEAN
+    lean_wave_loop<UNROLL_STEPS>(sc, stack, n, t_min, t_max, io);
+    return;
+#endif
     uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
     uint32_t mine = 0;
     const OrderedBounds B = OrderedWalk::bounds(t_min, t_max);

@@ -755,12 +755,17 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     }
     std::vector<GuideNode> guide_nodes;
     if (boxes_nested) walk_flags |= PT_WALK_BOXES_NESTED;
-    const bool guide_possible = want_guide && boxes_nested && ow_leaf_m_max <= 1e18 && walk.size() * sizeof(uint64_t) < 0x80000000ull;
+    // The guide tree's allocation holds the nodes and, right behind them, a second copy of the (padded) record stream: the
+    // ordered walk then reaches everything it fetches with a 32-bit offset from one base (pt_lean.h).  n leaves => n - 1 nodes.
+    const size_t walk_padded_bytes = walk.size() * sizeof(uint64_t);
+    const size_t guide_bytes_max = guide_leaves.size() * sizeof(GuideNode);
+    const bool guide_possible = want_guide && boxes_nested && ow_leaf_m_max <= 1e18 && walk_padded_bytes < 0x80000000ull &&
+                                guide_bytes_max + walk_padded_bytes < 0xFFFFFF00ull;
     bool has_guide = false;
     size_t n_guide_nodes = 0;
     if (guide_possible && ctx->guide_build_device && guide::usable(guide_leaves)) {
         n_guide_nodes = guide_leaves.size() - 1;
-        PT_HIP(ctx, ensure_buf(ctx->d_guide, n_guide_nodes * sizeof(GuideNode)));
+        PT_HIP(ctx, ensure_buf(ctx->d_guide, n_guide_nodes * sizeof(GuideNode) + walk_padded_bytes));
         const char* why = "";
         hipError_t e = guide_build_on_device(ctx->stream, guide_leaves, (GuideNode*)ctx->d_guide.p, &why);
         if (e != hipSuccess) {
@@ -770,10 +775,12 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
         has_guide = true;
     } else if (guide_possible && guide::build(guide_leaves, guide_nodes)) {
         n_guide_nodes = guide_nodes.size();
-        PT_HIP(ctx, ensure_buf(ctx->d_guide, guide_nodes.size() * sizeof(GuideNode)));
+        PT_HIP(ctx, ensure_buf(ctx->d_guide, guide_nodes.size() * sizeof(GuideNode) + walk_padded_bytes));
         PT_HIP(ctx, hipMemcpy(ctx->d_guide.p, guide_nodes.data(), guide_nodes.size() * sizeof(GuideNode), hipMemcpyHostToDevice));
         has_guide = true;
     }
+    if (has_guide)
+        PT_HIP(ctx, hipMemcpy((unsigned char*)ctx->d_guide.p + n_guide_nodes * sizeof(GuideNode), walk.data(), walk_padded_bytes, hipMemcpyHostToDevice));
     PT_HIP(ctx, ensure_buf(ctx->d_nodes, nodes.size() * sizeof(DevNode)));
     PT_HIP(ctx, ensure_buf(ctx->d_prims, prims.size() * sizeof(DevPrim)));
     PT_HIP(ctx, ensure_buf(ctx->d_aux, aux.size() * sizeof(double)));

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
 #endif
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_ORDERED_WAVES))) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
                                                                  uint32_t n_waves, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
-    __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
+    __shared__ uint32_t s_stack[PT_GUIDE_STACK_SLOTS * PT_BLOCK];
     const uint32_t wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t n = __builtin_amdgcn_readfirstlane(counts[wave]);
     RegionRayIo io{rays, hit_t, hit_prim, (size_t)wave * counts[n_waves]};
@@ -281,7 +281,7 @@ struct BatchRayIo { // a slice of the caller's arrays (AoS, as the C ABI takes t
 __global__ __launch_bounds__(PT_BLOCK) void trace_batch_ordered_kernel(DevScene sc, const double* __restrict__ origins,
                                                                        const double* __restrict__ dirs, uint32_t n, double t_min,
                                                                        double t_max, PtHitOut* __restrict__ out) {
-    __shared__ uint32_t s_stack[PT_GUIDE_STACK * PT_BLOCK];
+    __shared__ uint32_t s_stack[PT_GUIDE_STACK_SLOTS * PT_BLOCK];
     const OrderedScene os = ordered_scene(sc);
     const uint32_t waves = gridDim.x * (blockDim.x / PT_WAVE), wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t per_wave = (n + waves - 1u) / waves; // rays [wave * per_wave, ...) belong to this wave
