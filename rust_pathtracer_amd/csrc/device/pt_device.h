@@ -721,6 +721,11 @@ struct StreamWalk {
     }
     // the current record is a node: bvh.rs:108-110 (straight-line box test: no divergent early returns)
     __device__ __forceinline__ void step_node(const unsigned char* __restrict__ stream, uint32_t limit = 0xFFFFFFFFu) {
+        advance_node();
+        fetch(stream, limit);
+    }
+    // (the step without its fetch: for callers that keep the record elsewhere, pt_lean.h)
+    __device__ __forceinline__ void advance_node() {
 #ifdef PT_DEBUG_STEPS
         steps_nodes += 1;
 #endif
@@ -735,10 +740,13 @@ struct StreamWalk {
         lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
         miss |= hi <= lo;
         off = miss ? aux : off + PT_WK_NODE_BYTES;
-        fetch(stream, limit);
     }
     // the current record is a primitive (or the six sides of a box)
     __device__ __forceinline__ void step_leaf(const unsigned char* __restrict__ stream, uint32_t limit = 0xFFFFFFFFu) {
+        advance_leaf(stream);
+        fetch(stream, limit);
+    }
+    __device__ __forceinline__ void advance_leaf(const unsigned char* __restrict__ stream) {
 #ifdef PT_DEBUG_STEPS
         steps_leaves += 1;
 #endif
@@ -770,7 +778,6 @@ struct StreamWalk {
             accept(h, t, aux);
             off += PT_WK_RECT_BYTES;
         }
-        fetch(stream, limit);
     }
     __device__ __forceinline__ double result_t() const {
 #ifdef PT_DEBUG_STEPS

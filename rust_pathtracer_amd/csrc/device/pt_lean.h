@@ -18,8 +18,11 @@
 enum { PT_LW_IDLE = 0, PT_LW_GUIDE = 1, PT_LW_LEAF = 2, PT_LW_FINISH = 3, PT_LW_VERIFY = 4, PT_LW_LITERAL = 5, PT_LW_LITERAL_BEGIN = 6 };
 
 struct LeanWalk {
-    StreamWalk w;  // the ray, the best hit so far, and the fetched record (kind, aux, g[6]); inv / t_min / off: literal walk only
-    uint2 tail;    // bytes 56..63 of the fetch (triangle: the 7th double)
+    StreamWalk w;  // the ray and the best hit so far; its record fields (kind, aux, g[6]), inv, t_min and off: literal walk only
+    // The fetched 64 bytes as the four 16-byte loads deliver them -- header and first double | two doubles | two doubles | sixth
+    // double and the eight bytes behind it (a triangle's seventh double) -- so that every fetch site defines the same four
+    // register quads and nothing is copied after a load.
+    uint4 r0, r1, r2, r3;
     uint32_t best_parent; // stream offset of the node that is the best primitive's parent in the reference's tree
     uint32_t cur;         // offset (from OrderedScene::base) of the fetched record
     uint32_t mode, sp;
@@ -30,13 +33,15 @@ struct LeanWalk {
     __device__ __forceinline__ void fetch(const OrderedScene& sc, uint32_t off) {
         off = min(off, sc.fetch_limit); // (whatever the tables hold, no fetch leaves the allocation: it is padded by 128 bytes)
         const uint4* p = reinterpret_cast<const uint4*>(sc.base + off);
-        const uint4 a = p[0], b = p[1], c = p[2], e = p[3];
-        w.kind = a.x; w.aux = a.y;
-        w.g[0] = __hiloint2double((int)a.w, (int)a.z); w.g[1] = __hiloint2double((int)b.y, (int)b.x);
-        w.g[2] = __hiloint2double((int)b.w, (int)b.z); w.g[3] = __hiloint2double((int)c.y, (int)c.x);
-        w.g[4] = __hiloint2double((int)c.w, (int)c.z); w.g[5] = __hiloint2double((int)e.y, (int)e.x);
-        tail = make_uint2(e.z, e.w);
+        r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
         cur = off;
+    }
+    static __device__ __forceinline__ double f64_of(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
+    static __device__ __forceinline__ pt_f32x2 pair(uint32_t lo, uint32_t hi) {
+        pt_f32x2 r;
+        r.x = __uint_as_float(lo);
+        r.y = __uint_as_float(hi);
+        return r;
     }
     // The entry below the stack top (anything when the stack is empty): read at the start of a step, used at its end.
     __device__ __forceinline__ uint32_t peek(const uint32_t* stack) const { return stack[(max(sp, 1u) - 1u) * PT_BLOCK]; }
@@ -97,9 +102,9 @@ struct LeanWalk {
     __device__ __forceinline__ void step_guide(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
         const uint32_t popped = peek(stack);
         float e0, e1; // (the fetched 48 bytes: child 0's x, y, z pairs, then child 1's)
-        const bool h0 = slab(OrderedWalk::pair_of(w.g[0]), OrderedWalk::pair_of(w.g[1]), OrderedWalk::pair_of(w.g[2]), B.tmin_dn, e0);
-        const bool h1 = slab(OrderedWalk::pair_of(w.g[3]), OrderedWalk::pair_of(w.g[4]), OrderedWalk::pair_of(w.g[5]), B.tmin_dn, e1);
-        const uint32_t c0 = w.kind, c1 = w.aux;
+        const bool h0 = slab(pair(r0.z, r0.w), pair(r1.x, r1.y), pair(r1.z, r1.w), B.tmin_dn, e0);
+        const bool h1 = slab(pair(r2.x, r2.y), pair(r2.z, r2.w), pair(r3.x, r3.y), B.tmin_dn, e1);
+        const uint32_t c0 = r0.x, c1 = r0.y;
         const bool both = h0 && h1, swap = both && e1 < e0;
         const bool push = both && sp < PT_GUIDE_STACK;
         stack[sp * PT_BLOCK] = swap ? c0 : c1; // above the top; it only counts when sp moves (sp <= PT_GUIDE_STACK: the spare level)
@@ -123,15 +128,15 @@ struct LeanWalk {
         const uint32_t popped = peek(stack);
         const double bound_t = w.best_prim < 0 ? B.t_max : OrderedWalk::near(w.best_t);
         const V3 o = w.o, d = w.d;
-        const double* g = w.g;
+        const double g[6] = {f64_of(r0.z, r0.w), f64_of(r1.x, r1.y), f64_of(r1.z, r1.w), f64_of(r2.x, r2.y), f64_of(r2.z, r2.w), f64_of(r3.x, r3.y)};
         const double t_min = B.t_min;
-        const uint32_t kind = w.kind & PT_WK_KIND_MASK, aux = w.aux, link = (w.kind >> PT_WK_LINK_SHIFT) * 8u;
+        const uint32_t kind = r0.x & PT_WK_KIND_MASK, aux = r0.y, link = (r0.x >> PT_WK_LINK_SHIFT) * 8u;
         double t;
         if (kind == PT_WK_SPHERE) {
             consider(hit_sphere(g, o, d, t_min, bound_t, t), t, aux, link);
         } else if (kind == PT_WK_TRIANGLE) {
             const double* rest = reinterpret_cast<const double*>(sc.base + cur + 64u); // (cur <= fetch_limit: inside the padding)
-            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], __hiloint2double((int)tail.y, (int)tail.x), rest[0], rest[1]};
+            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], f64_of(r3.z, r3.w), rest[0], rest[1]};
             consider(hit_triangle(tri, o, d, t_min, bound_t, t), t, aux, link);
         } else if (kind == PT_WK_BOX6) {
             const double r0[5] = {g[2], g[0], g[3], g[1], g[4]}, r1[5] = {g[5], g[0], g[3], g[1], g[4]};
@@ -165,7 +170,7 @@ struct LeanWalk {
     // bvh.rs:18-35 on the box of P's parent node, operation for operation: OrderedWalk::step_verify
     __device__ __forceinline__ void step_verify(const OrderedBounds& B) {
         const V3 o = w.o, inv = v3(1.0 / w.d.x, 1.0 / w.d.y, 1.0 / w.d.z);
-        const double* g = w.g;
+        const double g[6] = {f64_of(r0.z, r0.w), f64_of(r1.x, r1.y), f64_of(r1.z, r1.w), f64_of(r2.x, r2.y), f64_of(r2.z, r2.w), f64_of(r3.x, r3.y)};
         double lo = B.t_min, hi = fmin(OrderedWalk::near(w.best_t), B.t_max);
         double t0 = (g[0] - o.x) * inv.x, t1 = (g[3] - o.x) * inv.x;
         lo = fmax((inv.x < 0.0) ? t1 : t0, lo); hi = fmin((inv.x < 0.0) ? t0 : t1, hi);
@@ -176,7 +181,7 @@ struct LeanWalk {
         t0 = (g[2] - o.z) * inv.z; t1 = (g[5] - o.z) * inv.z;
         lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
         miss |= hi <= lo;
-        mode = (miss || w.kind != PT_WK_NODE) ? (uint32_t)PT_LW_LITERAL_BEGIN : (uint32_t)PT_LW_IDLE; // IDLE: the reference reaches P and returns (P, best_t)
+        mode = (miss || r0.x != PT_WK_NODE) ? (uint32_t)PT_LW_LITERAL_BEGIN : (uint32_t)PT_LW_IDLE; // IDLE: the reference reaches P and returns (P, best_t)
     }
     // The literal walk (StreamWalk) from scratch.  A lane that turns to it has no more use for its guide stack: the ray's
     // reciprocals (bvh.rs:22) are parked in its first six slots, once, and read back by every literal step.
@@ -189,16 +194,23 @@ struct LeanWalk {
             stack[4 * PT_BLOCK] = (uint32_t)__double2loint(iz); stack[5 * PT_BLOCK] = (uint32_t)__double2hiint(iz);
             w.best_t = B.t_max;
             w.best_prim = -1;
-            w.off = 0;
-            w.fetch(stream, sc.stream_bytes); // StreamWalk::begin: the root record
+            sp = 0u;                        // (from here on: the literal walk's offset into the stream)
+            fetch(sc, sc.guide_bytes);      // StreamWalk::begin: the root record
             mode = PT_LW_LITERAL;
             return;
         }
+        // the StreamWalk's record lives in r0..r3 between steps (no registers of its own outside this function)
+        w.off = sp;
+        w.kind = r0.x & PT_WK_KIND_MASK; w.aux = r0.y;
+        w.g[0] = f64_of(r0.z, r0.w); w.g[1] = f64_of(r1.x, r1.y); w.g[2] = f64_of(r1.z, r1.w);
+        w.g[3] = f64_of(r2.x, r2.y); w.g[4] = f64_of(r2.z, r2.w); w.g[5] = f64_of(r3.x, r3.y);
         w.t_min = B.t_min;
         w.inv = v3(__hiloint2double((int)stack[1 * PT_BLOCK], (int)stack[0 * PT_BLOCK]), __hiloint2double((int)stack[3 * PT_BLOCK], (int)stack[2 * PT_BLOCK]),
                    __hiloint2double((int)stack[5 * PT_BLOCK], (int)stack[4 * PT_BLOCK]));
-        if (w.at_node()) w.step_node(stream, sc.stream_bytes);
-        else w.step_leaf(stream, sc.stream_bytes);
+        if (w.at_node()) w.advance_node();
+        else w.advance_leaf(stream);
+        sp = w.off;
         if (w.off >= sc.stream_bytes) mode = PT_LW_IDLE;
+        fetch(sc, sc.guide_bytes + w.off); // (clamped to the padding when the walk is over)
     }
 };
