@@ -266,7 +266,8 @@ struct DevScene {
     uint32_t walk_flags; // PT_WALK_*
     uint32_t has_procedural; // PT_PROC_*: which textures the scene has beyond solid colours
     const ShadePrim* shade_prims;
-    const unsigned char* guide; // the guide tree of the ordered walk (guide_tree.h), node 0 = root; null when there is none
+    const unsigned char* guide; // the guide tree of the ordered walk (guide_tree.h), node 0 = root, followed by a copy of the record
+                                // stream (one allocation: OrderedScene); null when there is none
     uint32_t guide_nodes;
     // which rays the ordered walk may take (computed at upload from the primitives' sizes, see pt_scene_upload):
     double ow_origin_limit; // |o|inf at most this ...
@@ -815,22 +816,20 @@ struct StreamWalk {
 #define PT_GUIDE_LEAF 0x80000000u
 #define PT_GUIDE_STACK 20 /* 20 KB of LDS per block: six blocks of the tail kernel (path.hip) fit a CU; deeper => literal walk */
 #define PT_GUIDE_STACK_SLOTS (PT_GUIDE_STACK + 1) /* levels the kernels allocate: one to spare for pt_lean.h's unconditional store */
-#define PT_GUIDE_ABS_SLACK 1e-37f /* see OrderedWalk::guide_slab */
-enum { PT_OW_IDLE = 0, PT_OW_GUIDE = 1, PT_OW_LEAF = 2, PT_OW_VERIFY = 3, PT_OW_LITERAL = 4, PT_OW_LITERAL_BEGIN = 5 };
-struct OrderedScene { // wave-uniform: what the ordered walk reads
-    const unsigned char* guide;  // guide tree: guide_nodes records of 64 bytes, node 0 = root
-    const unsigned char* stream; // record stream with parent links, padded by 128 bytes
-    uint32_t guide_nodes, stream_bytes;
+#define PT_GUIDE_ABS_SLACK 1e-37f /* see the box test's error budget at OrderedWalk below */
+// Wave-uniform: what the ordered walk reads.  The guide tree's allocation holds the nodes (64 bytes each, node 0 = root) and,
+// right behind them, a copy of the record stream with parent links (pt_scene_upload), so that everything the walk fetches is
+// `base` + a 32-bit offset.
+struct OrderedScene {
+    const unsigned char* base;
+    uint32_t guide_bytes;        // guide nodes * 64: where the stream copy starts
+    uint32_t stream_bytes;       // of the stream proper (128 bytes of padding follow)
+    uint32_t fetch_limit;        // guide_bytes + stream_bytes: the last offset a fetch may start at
     double origin_limit, tri_extent, od_limit; // DevScene::ow_*
-    // The guide tree's allocation also holds, right behind the nodes, a copy of the record stream (pt_scene_upload): everything
-    // the walk fetches is then `base` + a 32-bit offset (pt_lean.h).
-    const unsigned char* base;   // = guide
-    uint32_t guide_bytes;        // guide_nodes * 64: where the stream copy starts
-    uint32_t fetch_limit;        // guide_bytes + stream_bytes: the last offset a fetch may start at (128 bytes of padding follow)
 };
 __host__ __device__ inline OrderedScene ordered_scene(const DevScene& sc) {
-    return OrderedScene{sc.guide, sc.walk, sc.guide_nodes, sc.walk_bytes, sc.ow_origin_limit, sc.ow_tri_extent, sc.ow_od_limit,
-                        sc.guide, sc.guide_nodes * 64u, sc.guide_nodes * 64u + sc.walk_bytes};
+    return OrderedScene{sc.guide, sc.guide_nodes * 64u, sc.walk_bytes, sc.guide_nodes * 64u + sc.walk_bytes, sc.ow_origin_limit,
+                        sc.ow_tri_extent, sc.ow_od_limit};
 }
 #ifdef PT_DEBUG_PHASES /* debugging aid (pt_ordered.h): counters summed over all waves, read with pt_debug_read_phases */
 __device__ unsigned long long pt_debug_phase[32];
@@ -841,21 +840,8 @@ struct OrderedBounds {
     double t_min, t_max; // the caller's window (ray.rs:25: 0.001, +inf)
     float tmin_dn;       // t_min moved down for the guide tree's f32 box tests
 };
+// Arithmetic shared by the steps of the ordered walk (the walk itself: pt_lean.h LeanWalk).
 struct OrderedWalk {
-    StreamWalk w;     // the ray, the best hit so far, and the fetched 56 bytes (kind, aux, g[6]); w.inv and w.t_min are set by
-                      // the literal step only (no lane carries six registers of reciprocals through the guide traversal)
-    uint2 tail;       // bytes 56..63 of the fetch (triangle: the 7th double)
-    // (second_t, the nearest candidate other than the best one, lives in q[4].y as an f32 rounded DOWN: a candidate is then
-    // taken for a near tie -- and the ray handed to the literal walk -- within 1.2e-7 of the best hit instead of 1e-9)
-    uint32_t best_parent; // stream offset of the node that is the best primitive's parent in the reference's tree
-    uint32_t cur;         // LEAF: stream offset of the fetched record
-    uint32_t mode, sp;
-    // The ray for the guide tree's box tests, in f32 (guide_slab): the origin rounded, the reciprocal direction, and
-    // -(o - of) * invf, so that a slab parameter (l - o) / d is one subtraction and one fused multiply-add.
-    pt_f32x2 q[5]; // (of.x, of.y) (of.z, invf.x) (invf.y, invf.z) (nrinv.x, nrinv.y) (nrinv.z, second_t): see guide_slab
-#ifdef PT_DEBUG_STEPS
-    uint32_t steps_guide, steps_leaf, steps_verify, went_literal;
-#endif
     static __device__ __forceinline__ double near(double b) { return fma(fabs(b), 1e-9, b); }
     static __device__ __forceinline__ float f32_not_below(double x) { // >= x (x finite or +inf), up to PT_GUIDE_ABS_SLACK where the conversion underflows
         const float f = (float)x;
@@ -867,94 +853,6 @@ struct OrderedWalk {
     }
     static __device__ __forceinline__ OrderedBounds bounds(double t_min, double t_max) {
         return OrderedBounds{t_min, t_max, f32_not_above(t_min) - 2.0f * PT_GUIDE_ABS_SLACK};
-    }
-    // (a guide node's last eight bytes are unused: one load instruction less for 14 of a ray's 17 fetches -- the texture data
-    // path, not arithmetic, is the busiest unit of this walk)
-    __device__ __forceinline__ void fetch64(const unsigned char* __restrict__ p, bool with_tail) {
-        const uint2 hdr = *reinterpret_cast<const uint2*>(p);
-        const double2* q = reinterpret_cast<const double2*>(p + 8u);
-        const double2 a = q[0], b = q[1], c = q[2];
-        if (with_tail) tail = *reinterpret_cast<const uint2*>(p + 56u);
-        w.kind = hdr.x; w.aux = hdr.y;
-        w.g[0] = a.x; w.g[1] = a.y; w.g[2] = b.x; w.g[3] = b.y; w.g[4] = c.x; w.g[5] = c.y;
-    }
-    // Where the lane goes next, and ONE fetch for it (the four destinations differ only in an address):
-    //   `ref` if `have`, else the top of the stack, else -- the guide traversal is over -- nowhere (nothing was hit:
-    //   the reference misses as well), the literal walk (a tie, or `literal` forced), or P's parent box.
-    __device__ __forceinline__ void advance(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B, bool have, uint32_t ref, bool literal) {
-        if (!have && !literal && sp > 0) {
-            sp -= 1;
-            ref = stack[sp * PT_BLOCK];
-            have = true;
-        }
-        uint32_t off; // of the record in the stream, or the node index in the guide tree
-        if (have) {
-            const bool leaf = (ref & PT_GUIDE_LEAF) != 0u;
-            off = ref & ~PT_GUIDE_LEAF;
-            mode = leaf ? PT_OW_LEAF : PT_OW_GUIDE;
-            cur = leaf ? off : cur;
-        } else if (!literal && w.best_prim < 0 && q[4].y == __builtin_huge_valf()) {
-            mode = PT_OW_IDLE; // no primitive test reported anything
-            off = 0;
-        } else if (literal || !((double)q[4].y > near(w.best_t))) {
-            mode = PT_OW_LITERAL_BEGIN; // StreamWalk::begin; the root record is a node (kind word 0)
-            w.best_t = B.t_max;
-            w.best_prim = -1;
-            w.off = 0;
-            off = 0;
-#ifdef PT_DEBUG_STEPS
-            went_literal = 1;
-#endif
-        } else {
-            mode = PT_OW_VERIFY;
-            off = best_parent;
-        }
-#ifdef PT_DEBUG_BOUNDS
-        if (mode != PT_OW_IDLE && (mode == PT_OW_GUIDE ? off >= sc.guide_nodes : off >= sc.stream_bytes)) {
-            printf("OrderedWalk: mode %u off %u out of range (guide %u stream %u) have %d literal %d sp %u\n", mode, off, sc.guide_nodes, sc.stream_bytes, (int)have, (int)literal, sp);
-            mode = PT_OW_IDLE;
-        }
-#endif
-        // (the clamps cost two instructions and make a fetch outside the tables impossible whatever the tables hold)
-        const unsigned char* p = mode == PT_OW_GUIDE ? sc.guide + (size_t)min(off, sc.guide_nodes - 1u) * 64u : sc.stream + min(off, sc.stream_bytes);
-        if (mode != PT_OW_IDLE) fetch64(p, mode != PT_OW_GUIDE);
-    }
-    __device__ __forceinline__ void begin(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B, V3 o, V3 d) {
-        w.o = o; w.d = d;
-        w.best_t = B.t_max;
-        w.best_prim = -1;
-        w.off = 0;
-        best_parent = 0; cur = 0; sp = 0;
-#ifdef PT_DEBUG_STEPS
-        w.steps_nodes = w.steps_leaves = 0;
-        steps_guide = steps_leaf = steps_verify = went_literal = 0;
-#endif
-        // Ordinary rays only: direction components in [2^-60, 2^100], origin within the scene's limit (at most 1e18).  Then (with
-        // the scene's coordinates finite and below 1e18, checked at upload) no primitive test and no box test can overflow or produce
-        // a NaN, which is what the guide's arithmetic, the nesting argument AND the premise "a primitive that reports a
-        // hit is crossed inside its box" rest on: the reference accepts a sphere whose discriminant is inf - inf = NaN
-        // (geometry.rs:132-148: every comparison with NaN is false) wherever the ray is, and a NaN bound then lets any
-        // later hit replace a nearer one.  The same premise fails without any NaN when the origin is far from a
-        // primitive relative to the primitive's size: the tests cancel and report hits for rays that pass whole units
-        // beside it (a sphere of radius 0.5 seen from 1e9 away), outside the 1e-5 padding of its guide box, where the
-        // reference -- which tests it whenever its parent's box is crossed -- still takes the hit.  The upload turns the
-        // sizes of the scene's primitives into the two limits below.  All other rays take the literal walk.
-        const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
-        const double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), dmax = fmax(fmax(ax, ay), az), dmin = fmin(fmin(ax, ay), az);
-        const bool ordinary = dmin >= 0x1p-60 && dmax <= 0x1p100 && omax <= sc.origin_limit && (omax + sc.tri_extent) * dmax <= sc.od_limit &&
-                              B.t_min == B.t_min && B.t_max == B.t_max;
-        const double oc[3] = {o.x, o.y, o.z}, dc[3] = {d.x, d.y, d.z};
-        float of[3], invf[3], nrinv[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            of[k] = (float)oc[k];
-            const float rf = (float)(oc[k] - (double)of[k]); // the difference is exact in f64; its rounding errs by 2^-48 |o|
-            invf[k] = __builtin_amdgcn_rcpf((float)dc[k]);   // 1/d to 3 * 2^-24 (conversion 2^-24, v_rcp_f32 one ulp)
-            nrinv[k] = -(rf * invf[k]);
-        }
-        q[0].x = of[0]; q[0].y = of[1]; q[1].x = of[2]; q[1].y = invf[0]; q[2].x = invf[1]; q[2].y = invf[2];
-        q[3].x = nrinv[0]; q[3].y = nrinv[1]; q[4].x = nrinv[2]; q[4].y = __builtin_huge_valf(); // no second candidate yet
-        advance(sc, stack, B, ordinary, 0u, !ordinary);
     }
     // ---- The guide tree's box test, in packed f32.  It only has to be CONSERVATIVE: accept every child box (stored as f32,
     // rounded outwards, padded by 1e-5 of the leaf's largest coordinate m) that the ray crosses within [t_min, bound]; what
@@ -982,154 +880,6 @@ struct OrderedWalk {
         : "v"(planes), "v"(c_of), "v"(c_inv), "v"(c_nr))
     static __device__ __forceinline__ float raw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ float raw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-    __device__ __forceinline__ bool guide_slab(pt_f32x2 x, pt_f32x2 y, pt_f32x2 z, float bound, float tmin_dn, float& entry) const {
-        pt_f32x2 tx, ty, tz;
-        PT_PK_SLAB(tx, x, q[0], 0, q[1], 1, q[3], 0);
-        PT_PK_SLAB(ty, y, q[0], 1, q[2], 0, q[3], 1);
-        PT_PK_SLAB(tz, z, q[1], 0, q[2], 1, q[4], 0);
-        // (min / max as instructions as well: behind fminf / fmaxf the compiler first quiets a possible signalling NaN in each input
-        // that comes out of an asm statement -- six extra instructions per box for values that are never NaN)
-        const float nx = raw_min(tx.x, tx.y), ny = raw_min(ty.x, ty.y), nz = raw_min(tz.x, tz.y);
-        const float fx = raw_max(tx.x, tx.y), fy = raw_max(ty.x, ty.y), fz = raw_max(tz.x, tz.y);
-        float tn, tf;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tn) : "v"(nx), "v"(ny), "v"(nz));
-        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tf) : "v"(fx), "v"(fy), "v"(fz));
-        tn = __builtin_fmaf(__builtin_fabsf(tn), -5e-7f, tn);
-        tf = __builtin_fmaf(__builtin_fabsf(tf), 5e-7f, tf);
-        entry = tn;
-        return tn - 2.0f * PT_GUIDE_ABS_SLACK <= __builtin_fminf(tf, bound) && tf >= tmin_dn;
-    }
-    static __device__ __forceinline__ pt_f32x2 pair_of(double packed) {
-        pt_f32x2 r;
-        r.x = __int_as_float(__double2loint(packed));
-        r.y = __int_as_float(__double2hiint(packed));
-        return r;
-    }
-    __device__ __forceinline__ void step_guide(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
-#ifdef PT_DEBUG_STEPS
-        steps_guide += 1;
-#endif
-        // near(best) = best (1 + 1e-9) is what the argument needs the culling bound to reach; 2^-23 more covers the rounding to f32
-        const float bound = f32_not_below(near(w.best_t)) + PT_GUIDE_ABS_SLACK;
-        float e0, e1; // (the fetched 48 bytes: child 0's x, y, z pairs, then child 1's)
-        const bool h0 = guide_slab(pair_of(w.g[0]), pair_of(w.g[1]), pair_of(w.g[2]), bound, B.tmin_dn, e0);
-        const bool h1 = guide_slab(pair_of(w.g[3]), pair_of(w.g[4]), pair_of(w.g[5]), bound, B.tmin_dn, e1);
-        const uint32_t c0 = w.kind, c1 = w.aux;
-        const bool both = h0 && h1, swap = both && e1 < e0;
-#if defined(PT_DEBUG_PHASES) && !defined(PT_DEBUG_PHASES_TIME_ONLY)
-        {
-            const unsigned long long m0 = __builtin_amdgcn_ballot_w64(!h0 && !h1), m2 = __builtin_amdgcn_ballot_w64(both);
-            const unsigned long long mh = __builtin_amdgcn_ballot_w64(w.best_prim >= 0), mh0 = __builtin_amdgcn_ballot_w64(w.best_prim >= 0 && !h0 && !h1);
-            if ((threadIdx.x & 63u) == 0u) {
-                atomicAdd(&pt_debug_phase[16], (unsigned long long)__builtin_popcountll(m0));
-                atomicAdd(&pt_debug_phase[17], (unsigned long long)__builtin_popcountll(m2));
-                atomicAdd(&pt_debug_phase[18], (unsigned long long)__builtin_popcountll(mh));
-                atomicAdd(&pt_debug_phase[19], (unsigned long long)__builtin_popcountll(mh0));
-            }
-        }
-#endif
-        const bool overflow = both && sp >= PT_GUIDE_STACK;
-        if (both && !overflow) {
-            stack[sp * PT_BLOCK] = swap ? c0 : c1;
-            sp += 1;
-        }
-        advance(sc, stack, B, (h0 || h1) && !overflow, (swap || !h0) ? c1 : c0, overflow);
-    }
-    // a candidate from a primitive test run with the bound near(best)
-    __device__ __forceinline__ void consider(bool hit, double t, uint32_t prim, uint32_t link) {
-        if (!hit) return;
-        if (t != t) { // cannot happen for an ordinary ray (see begin); if it does, the literal walk decides
-            q[4].y = -__builtin_huge_valf();
-        } else if ((int32_t)prim == w.best_prim) {
-            // the best primitive again, through another of its pieces' boxes (guide_tree.h split_pieces): same test, same t
-        } else if (t < w.best_t || w.best_prim < 0) {
-            if (w.best_prim >= 0) q[4].y = __builtin_fminf(q[4].y, f32_not_above(w.best_t) - PT_GUIDE_ABS_SLACK);
-            w.best_t = t; w.best_prim = (int32_t)prim; best_parent = link;
-        } else {
-            q[4].y = __builtin_fminf(q[4].y, f32_not_above(t) - PT_GUIDE_ABS_SLACK);
-        }
-    }
-    __device__ __forceinline__ void step_leaf(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
-#ifdef PT_DEBUG_STEPS
-        steps_leaf += 1;
-#endif
-        const double bound = w.best_prim < 0 ? B.t_max : near(w.best_t);
-        const V3 o = w.o, d = w.d;
-        const double* g = w.g;
-        const double t_min = B.t_min;
-        const uint32_t kind = w.kind & PT_WK_KIND_MASK, aux = w.aux, link = (w.kind >> PT_WK_LINK_SHIFT) * 8u;
-        double t;
-        if (kind == PT_WK_SPHERE) {
-            consider(hit_sphere(g, o, d, t_min, bound, t), t, aux, link);
-        } else if (kind == PT_WK_TRIANGLE) {
-            const double* rest = reinterpret_cast<const double*>(sc.stream + min(cur, sc.stream_bytes) + 64u);
-            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], __hiloint2double((int)tail.y, (int)tail.x), rest[0], rest[1]};
-            consider(hit_triangle(tri, o, d, t_min, bound, t), t, aux, link);
-        } else if (kind == PT_WK_BOX6) {
-            const double r0[5] = {g[2], g[0], g[3], g[1], g[4]}, r1[5] = {g[5], g[0], g[3], g[1], g[4]};
-            const double r2[5] = {g[1], g[0], g[3], g[2], g[5]}, r3[5] = {g[4], g[0], g[3], g[2], g[5]};
-            const double r4[5] = {g[0], g[1], g[4], g[2], g[5]}, r5[5] = {g[3], g[1], g[4], g[2], g[5]};
-            // the bound is not tightened between the six sides: all candidates within near(best) must be seen
-            consider(hit_rect(r0, o.z, d.z, o.x, d.x, o.y, d.y, t_min, bound, t), t, aux, link);
-            consider(hit_rect(r1, o.z, d.z, o.x, d.x, o.y, d.y, t_min, bound, t), t, aux + 1u, link);
-            consider(hit_rect(r2, o.y, d.y, o.x, d.x, o.z, d.z, t_min, bound, t), t, aux + 2u, link);
-            consider(hit_rect(r3, o.y, d.y, o.x, d.x, o.z, d.z, t_min, bound, t), t, aux + 3u, link);
-            consider(hit_rect(r4, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux + 4u, link);
-            consider(hit_rect(r5, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux + 5u, link);
-        } else if (kind == PT_WK_RECT_XY) {
-            consider(hit_rect(g, o.z, d.z, o.x, d.x, o.y, d.y, t_min, bound, t), t, aux, link);
-        } else if (kind == PT_WK_RECT_XZ) {
-            consider(hit_rect(g, o.y, d.y, o.x, d.x, o.z, d.z, t_min, bound, t), t, aux, link);
-        } else {
-            consider(hit_rect(g, o.x, d.x, o.y, d.y, o.z, d.z, t_min, bound, t), t, aux, link);
-        }
-        advance(sc, stack, B, false, 0u, false);
-    }
-    __device__ __forceinline__ void step_verify(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
-#ifdef PT_DEBUG_STEPS
-        steps_verify += 1;
-#endif
-        // bvh.rs:18-35 on the box of P's parent node, operation for operation (the reciprocals as the reference forms them at
-        // every node), with a bound the reference's cannot be below
-        const V3 o = w.o, inv = v3(1.0 / w.d.x, 1.0 / w.d.y, 1.0 / w.d.z);
-        const double* g = w.g;
-        double lo = B.t_min, hi = fmin(near(w.best_t), B.t_max);
-        double t0 = (g[0] - o.x) * inv.x, t1 = (g[3] - o.x) * inv.x;
-        lo = fmax((inv.x < 0.0) ? t1 : t0, lo); hi = fmin((inv.x < 0.0) ? t0 : t1, hi);
-        bool miss = hi <= lo;
-        t0 = (g[1] - o.y) * inv.y; t1 = (g[4] - o.y) * inv.y;
-        lo = fmax((inv.y < 0.0) ? t1 : t0, lo); hi = fmin((inv.y < 0.0) ? t0 : t1, hi);
-        miss |= hi <= lo;
-        t0 = (g[2] - o.z) * inv.z; t1 = (g[5] - o.z) * inv.z;
-        lo = fmax((inv.z < 0.0) ? t1 : t0, lo); hi = fmin((inv.z < 0.0) ? t0 : t1, hi);
-        miss |= hi <= lo;
-        if (miss || w.kind != PT_WK_NODE) advance(sc, stack, B, false, 0u, true);
-        else mode = PT_OW_IDLE; // the reference reaches P: it returns (P, best_t)
-    }
-    // A lane that turns to the literal walk has no more use for its guide stack: the ray's reciprocals (bvh.rs:22, formed
-    // by the reference at every node) are parked in its first six slots, once, and read back by every literal step.
-    __device__ __forceinline__ void step_literal(const OrderedScene& sc, uint32_t* stack, const OrderedBounds& B) {
-        if (mode == PT_OW_LITERAL_BEGIN) {
-            const double ix = 1.0 / w.d.x, iy = 1.0 / w.d.y, iz = 1.0 / w.d.z;
-            stack[0 * PT_BLOCK] = (uint32_t)__double2loint(ix); stack[1 * PT_BLOCK] = (uint32_t)__double2hiint(ix);
-            stack[2 * PT_BLOCK] = (uint32_t)__double2loint(iy); stack[3 * PT_BLOCK] = (uint32_t)__double2hiint(iy);
-            stack[4 * PT_BLOCK] = (uint32_t)__double2loint(iz); stack[5 * PT_BLOCK] = (uint32_t)__double2hiint(iz);
-            mode = PT_OW_LITERAL;
-        }
-        w.t_min = B.t_min;
-        w.inv = v3(__hiloint2double((int)stack[1 * PT_BLOCK], (int)stack[0 * PT_BLOCK]), __hiloint2double((int)stack[3 * PT_BLOCK], (int)stack[2 * PT_BLOCK]),
-                   __hiloint2double((int)stack[5 * PT_BLOCK], (int)stack[4 * PT_BLOCK])); // parked by advance()
-        if (w.at_node()) w.step_node(sc.stream, sc.stream_bytes);
-        else w.step_leaf(sc.stream, sc.stream_bytes);
-        if (w.off >= sc.stream_bytes) mode = PT_OW_IDLE;
-    }
-    __device__ __forceinline__ double result_t() const {
-#if defined(PT_DEBUG_STEPS) && !defined(PT_DEBUG_SLOW)
-        return (double)steps_guide + 1e3 * (double)steps_leaf + 1e6 * (double)steps_verify + 1e9 * (double)(w.steps_nodes + w.steps_leaves) + 1e14 * (double)went_literal;
-#else
-        return w.best_t;
-#endif
-    }
 };
 
 __device__ __forceinline__ void traverse_walk(const unsigned char* __restrict__ walk, uint32_t walk_bytes, uint32_t walk_flags,

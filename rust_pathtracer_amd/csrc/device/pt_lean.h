@@ -1,7 +1,7 @@
-// pt_lean.h -- the ordered walk (pt_device.h, "the ordered walk": the four numbered points there are what makes its answer the
-// reference's, bvh.rs:107-121) with its per-step code written for the instruction count.  Same traversal, same tests, same proof
-// step, same fallback -- results are identical by construction and checked bit for bit by the GPU suite; what differs from
-// OrderedWalk is only how a step is spelt:
+// pt_lean.h -- the ordered walk, per lane (pt_device.h, "the ordered walk": the four numbered points there are what makes its
+// answer the reference's, bvh.rs:107-121), with its per-step code written for the instruction count (rounds 1-2 spelt a box
+// step as nested branches: 109 VALU + 102 SALU instructions; this form: 63 + ~20, same traversal, same tests, same proof step,
+// same fallback, bit-identical results on the whole GPU suite):
 //   * The guide tree and a copy of the record stream sit in ONE allocation (guide nodes first), so a lane's next fetch is a
 //     32-bit offset from one scalar base whatever it points at -- no per-lane 64-bit pointer select.
 //   * A step has no branches.  The far child is stored above the stack top whether or not it is wanted (the array has one
@@ -11,7 +11,8 @@
 //     (PT_LW_FINISH), once per ray, instead of being woven into every step.
 //   * The f32 culling bound is kept in a register and refreshed when the best hit changes (a primitive test), not recomputed
 //     from the f64 hit distance at every box step.
-// Measured on gfx950: 109 -> see profiles/r03_* VALU instructions per box step.
+// Modes of a lane: IDLE (no ray), GUIDE (a guide node's two child boxes are in r0..r3), LEAF (a primitive record is), FINISH (the
+// traversal is over), VERIFY (the box of the best primitive's parent node is), LITERAL(_BEGIN) (the per-lane literal walk).
 #pragma once
 #include "pt_device.h"
 
@@ -61,7 +62,16 @@ struct LeanWalk {
         w.best_prim = -1;
         w.off = 0;
         best_parent = 0; sp = 0;
-        // which rays may take the ordered walk at all: OrderedWalk::begin
+        // Ordinary rays only: direction components in [2^-60, 2^100], origin within the scene's limit (at most 1e18).  Then (with
+        // the scene's coordinates finite and below 1e18, checked at upload) no primitive test and no box test can overflow or produce
+        // a NaN, which is what the guide's arithmetic, the nesting argument AND the premise "a primitive that reports a
+        // hit is crossed inside its box" rest on: the reference accepts a sphere whose discriminant is inf - inf = NaN
+        // (geometry.rs:132-148: every comparison with NaN is false) wherever the ray is, and a NaN bound then lets any
+        // later hit replace a nearer one.  The same premise fails without any NaN when the origin is far from a
+        // primitive relative to the primitive's size: the tests cancel and report hits for rays that pass whole units
+        // beside it (a sphere of radius 0.5 seen from 1e9 away), outside the 1e-5 padding of its guide box, where the
+        // reference -- which tests it whenever its parent's box is crossed -- still takes the hit.  The upload turns the
+        // sizes of the scene's primitives into the two limits below.  All other rays take the literal walk.
         const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
         const double omax = fmax(fmax(fabs(o.x), fabs(o.y)), fabs(o.z)), dmax = fmax(fmax(ax, ay), az), dmin = fmin(fmin(ax, ay), az);
         const bool ordinary = dmin >= 0x1p-60 && dmax <= 0x1p100 && omax <= sc.origin_limit && (omax + sc.tri_extent) * dmax <= sc.od_limit &&

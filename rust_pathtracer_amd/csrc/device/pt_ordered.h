@@ -1,16 +1,12 @@
-// pt_ordered.h -- the wave loop of the ordered walk (pt_device.h OrderedWalk), shared by the trace kernels (trace.hip)
-// and the per-wave tail of the bounce loop (path.hip).
+// pt_ordered.h -- the wave loop of the ordered walk (pt_device.h "the ordered walk"; the per-lane steps: pt_lean.h), shared by
+// the trace kernels (trace.hip) and the per-wave tail of the bounce loop (path.hip).
 #pragma once
 #include "pt_launch.h"
 #include "pt_lean.h"
 
-// 1: the walk of pt_lean.h (the default); 0: OrderedWalk as written in pt_device.h (kept for A/B builds, scratch/build_variant.sh)
-#ifndef PT_ORDERED_LEAN
-#define PT_ORDERED_LEAN 1
-#endif
-
-// Measured on SphereField (1080p, 32 spp): handing out rays when 40 lanes are idle, primitive tests when 16 lanes wait
-// for one, four box tests per round: 26.9 ms of trace per frame (16 / 24 / 4, the stream walk's values: 29.7 ms).
+// Thresholds of the loop.  Measured on SphereField (1080p, 32 spp) in round 1: handing out rays when 40 lanes are idle, primitive
+// tests when 16 lanes wait for one, four box tests per round: 26.9 ms of trace per frame (16 / 24 / 4, the stream walk's
+// values: 29.7 ms); swept again in round 3 on the lean steps (profiles/r03_lean_walk_thresholds.txt): everything within 3 %.
 #ifndef PT_ORD_REFILL_LANES
 #define PT_ORD_REFILL_LANES 40
 #endif
@@ -20,15 +16,8 @@
 #ifndef PT_ORD_LEAF_LANES
 #define PT_ORD_LEAF_LANES 16
 #endif
-// Larger scenes, ordered: nearest-first over the guide tree, then the proof that the reference's walk agrees
-// (pt_device.h OrderedWalk).  Same refill scheme as trace_stream_kernel; a lane's pending far children wait on a stack in
-// LDS laid out [level][thread].  The wave runs one kind of step at a time -- box tests (guide and verification),
-// primitive tests, or the literal walk; every step ends by issuing the lane's next fetch, so lanes that sit out a round
-// are waiting for memory anyway.
-// `io` supplies ray k of this wave's n rays and takes its result: the render kernel's region of the ray stream, or a
-// slice of the caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
-#ifndef PT_ORD_VERIFY_LANES
-#define PT_ORD_VERIFY_LANES 12
+#ifndef PT_LW_FINISH_LANES
+#define PT_LW_FINISH_LANES 12 /* end-of-traversal decisions and proof steps run when this many lanes wait for one */
 #endif
 #ifdef PT_DEBUG_PHASES /* debugging aid: rounds and active lanes per kind of step, summed over all waves (read with pt_debug_read_phases) */
 #ifdef PT_DEBUG_PHASES_TIME_ONLY /* (the counters' atomics would be most of what the clocks see) */
@@ -67,13 +56,15 @@
 #define PT_PHASE_DECL do {} while (0)
 #define PT_PHASE_FLUSH do {} while (0)
 #endif
+// Larger scenes, ordered: nearest-first over the guide tree, then the proof that the reference's walk agrees (pt_device.h).  Same
+// refill scheme as trace_stream_kernel; a lane's pending far children wait on a stack in LDS laid out [level][thread].  The wave
+// runs ONE kind of step per round -- hand out rays, box tests (PT_ORD_NODE_STEPS in a row), primitive tests, end-of-traversal
+// decisions + proof steps, or the literal walk -- chosen from how many lanes want which; every step ends by issuing the lane's
+// next fetch, so lanes that sit out a round are waiting for memory anyway.
+// `io` supplies ray k of this wave's n rays and takes its result: the render kernel's region of the ray stream, or a slice of the
+// caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
 // UNROLL_STEPS: the box steps of a round as straight-line code (the trace kernels: SphereField 32 spp 25.6 against 26.3 ms) or as a
 // loop (the tail kernel, which also carries the shading code: fewer spilled values, 1M mesh 16 spp tail 7.8 -> 6.8 ms).
-#ifndef PT_LW_FINISH_LANES
-#define PT_LW_FINISH_LANES 12
-#endif
-// The wave loop over pt_lean.h's walk: one kind of step per round -- hand out rays, box tests (PT_ORD_NODE_STEPS in a row),
-// primitive tests, end-of-traversal decisions + proof steps, or the literal walk -- chosen from how many lanes want which.
 template <bool UNROLL_STEPS, class RayIo>
 __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
     uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
@@ -155,87 +146,7 @@ __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t*
 
 template <bool UNROLL_STEPS = true, class RayIo>
 __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
-#if PT_ORDERED_LEAN
     lean_wave_loop<UNROLL_STEPS>(sc, stack, n, t_min, t_max, io);
-    return;
-#endif
-    uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
-    uint32_t mine = 0;
-    const OrderedBounds B = OrderedWalk::bounds(t_min, t_max);
-    OrderedWalk w;
-#ifdef PT_DEBUG_BOUNDS
-    w.w.lim = sc.stream_bytes;
-#endif
-    w.begin(sc, stack, B, v3(0, 0, 0), v3(1, 1, 1));
-    w.mode = PT_OW_IDLE;
-    PT_PHASE_DECL;
-    for (;;) {
-        PT_PHASE_CLOCK(c_top);
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE);
-        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (next < n && n_idle >= PT_ORD_REFILL_LANES) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-            const uint32_t k = next + rank;
-            PT_PHASE_COUNT(0, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_IDLE && k < n));
-            if (w.mode == PT_OW_IDLE && k < n) {
-                mine = k;
-                V3 o, d;
-                io.load(k, o, d);
-                w.begin(sc, stack, B, o, d);
-            }
-            next = min(n, next + n_idle);
-        } else if (n_idle == 64u) {
-            break;
-        }
-        PT_PHASE_CLOCK(c_refilled);
-        PT_PHASE_TIME(0, c_top, c_refilled);
-        const uint32_t mode_before = w.mode;
-        // One kind of step per round: guide-tree box tests, the proof step (it forms the ray's three reciprocals: run when
-        // enough lanes have gathered for it, or nothing else is left to do), primitive tests, or the literal walk.
-        const uint32_t n_guide = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE));
-        const uint32_t n_verify = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_VERIFY));
-        const uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
-        const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode >= PT_OW_LITERAL));
-        PT_PHASE_CLOCK(c_chosen);
-        PT_PHASE_TIME(5, c_refilled, c_chosen);
-        const int phase_slot = (n_verify >= PT_ORD_VERIFY_LANES || (n_verify != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u)) ? 1
-                               : (n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) ? 2 : (n_leaf != 0u && n_leaf >= n_literal) ? 3 : 4;
-        (void)phase_slot;
-        if (n_verify >= PT_ORD_VERIFY_LANES || (n_verify != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u)) {
-            PT_PHASE_COUNT(1, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_VERIFY));
-            if (w.mode == PT_OW_VERIFY) w.step_verify(sc, stack, B);
-        } else if (n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES) {
-            if (UNROLL_STEPS) {
-#pragma unroll
-                for (int r = 0; r < PT_ORD_NODE_STEPS; ++r) {
-                    PT_PHASE_COUNT(2 + r, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_GUIDE));
-                    if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack, B);
-                }
-            } else {
-#pragma nounroll
-                for (int r = 0; r < PT_ORD_NODE_STEPS; ++r)
-                    if (w.mode == PT_OW_GUIDE) w.step_guide(sc, stack, B);
-            }
-        } else if (n_leaf != 0u && n_leaf >= n_literal) {
-            PT_PHASE_COUNT(6, __builtin_amdgcn_ballot_w64(w.mode == PT_OW_LEAF));
-            if (w.mode == PT_OW_LEAF) w.step_leaf(sc, stack, B);
-        } else {
-            PT_PHASE_COUNT(7, __builtin_amdgcn_ballot_w64(w.mode >= PT_OW_LITERAL));
-            if (w.mode >= PT_OW_LITERAL) w.step_literal(sc, stack, B); // rare: one step per round keeps the kernel small
-        }
-#ifdef PT_DEBUG_SLOW /* with PT_DEBUG_STEPS: name the rays that take more than PT_DEBUG_SLOW steps */
-        if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE &&
-            w.steps_guide + w.steps_leaf + w.steps_verify + w.w.steps_nodes + w.w.steps_leaves > PT_DEBUG_SLOW)
-            printf("slow ray: guide %u leaf %u verify %u literal %u + %u (went %u) n %u o %.17g %.17g %.17g d %.17g %.17g %.17g t %.17g prim %d\n", w.steps_guide, w.steps_leaf,
-                   w.steps_verify, w.w.steps_nodes, w.w.steps_leaves, w.went_literal, n, w.w.o.x, w.w.o.y, w.w.o.z, w.w.d.x, w.w.d.y, w.w.d.z, w.w.best_t, w.w.best_prim);
-#endif
-        PT_PHASE_CLOCK(c_stepped);
-        PT_PHASE_TIME(phase_slot, c_chosen, c_stepped);
-        if (mode_before != PT_OW_IDLE && w.mode == PT_OW_IDLE) io.store(mine, w.w.o, w.w.d, w.result_t(), w.w.best_prim);
-        PT_PHASE_CLOCK(c_stored);
-        PT_PHASE_TIME(6, c_stepped, c_stored);
-    }
-    PT_PHASE_FLUSH;
 }
 
 struct RegionRayIo { // the wave's region of the wavefront ray stream
