@@ -326,12 +326,18 @@ def kernel_entries(tot, pmc, rays_per_s_whole, n_cus, clock_hz):
     return out
 
 
-def issue_roofline(pmc, mrays_per_gpu, n_cus, clock_hz):
-    """The bound the pipeline actually runs against on small scenes: VALU instruction issue.  Wave-instructions per 64
-    ray segments from the PMC counters (SQ_INSTS_VALU / rays * 64, trace + shade), CYCLES_PER_VALU cycles each per SIMD."""
+def issue_roofline(pmc, tot, mrays_per_gpu, n_cus, clock_hz):
+    """The bound the pipeline actually runs against: VALU instruction issue.  Wave-instructions per 64 ray segments from the PMC
+    counters (SQ_INSTS_VALU / rays * 64 of each kernel, weighted by the rays that kernel traced in THIS run: trace + shade for the
+    bounces launched separately, the tail launch for the rest), CYCLES_PER_VALU cycles each per SIMD.  Raygen, fold and resolve
+    are not in it (a few per cent of a frame's instructions)."""
     try:
-        valu = pmc["trace_kernel"]["valu_per_64_rays"] + pmc["shade_kernel"]["valu_per_64_rays"]
-    except (KeyError, TypeError):
+        rw, rt = tot["rays_wavefront"], tot["rays_tail"]
+        valu = (pmc["trace_kernel"]["valu_per_64_rays"] + pmc["shade_kernel"]["valu_per_64_rays"]) * rw
+        if rt:
+            valu += pmc["path_kernel"]["valu_per_64_rays"] * rt
+        valu /= (rw + rt)
+    except (KeyError, TypeError, ZeroDivisionError):
         return None
     peak = 64.0 * n_cus * SIMDS_PER_CU * clock_hz / (valu * CYCLES_PER_VALU) / 1e6  # Mrays/s
     return {"bound": "valu_issue", "achieved": round(mrays_per_gpu, 1), "peak": round(peak, 1), "unit": "Mrays/s",
@@ -535,7 +541,7 @@ def main():
                                        + (" -- REHEARSAL: workers share a GPU, buffers summed through the host, not a multi-GPU measurement" if rehearsal else "")),
                        "rays_per_frame": rays_total // (args.steps * frames_per_step)},
             "roofline": roofline,
-            "issue_roofline": issue_roofline(pmc, mrays / world, n_cus, clock_hz),
+            "issue_roofline": issue_roofline(pmc, tot, mrays / world, n_cus, clock_hz),
             # union of each kernel's launch intervals on GPU 0 (with several lanes launches overlap: the sums of launch
             # durations, roofline.kernels[].launch_ms_sum, can exceed the frame)
             "kernel_busy_ms_per_step": {"trace": round(tot["ms_busy_trace"] / profiled_steps, 3), "shade": round(tot["ms_busy_shade"] / profiled_steps, 3),

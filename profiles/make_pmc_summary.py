@@ -10,6 +10,8 @@ raw = json.load(open(raw_path))
 line = next(l for l in open(log_path) if l.startswith("{") and '"rays_per_frame"' in l)
 bench = json.loads(line)
 rays = float(bench["config"]["rays_per_frame"])
+# rays each kernel traced in that run (round 3 on: bench.py splits rays_per_bounce by PtStats.tail_from)
+rays_of = {e["kernel"]: float(e["rays"]) for e in (bench.get("roofline") or {}).get("kernels", []) if "rays" in e}
 here = os.path.dirname(os.path.abspath(__file__))
 path = os.path.join(here, "pmc_summary.json")
 doc = json.load(open(path)) if os.path.exists(path) else {}
@@ -30,9 +32,10 @@ for key, prefixes in (("trace_kernel", ("trace_walk_kernel", "trace_ordered_kern
     g = lambda c: r[c]["sum"] if c in r else None
     f, w = g("FETCH_SIZE") * 1024 * 2, g("WRITE_SIZE") * 1024
     e = {"rocprof_name": name, "fetch_bytes": f, "write_bytes": w, "dispatches": r["FETCH_SIZE"]["dispatches"]}
-    if key != "path_kernel":  # (a tail launch covers many bounces: its rays are not split out)
-        e.update({"hbm_bytes_per_ray": round((f + w) / rays, 2), "valu_per_64_rays": round(g("SQ_INSTS_VALU") / (rays / 64), 1),
-                  "salu_per_64_rays": round(g("SQ_INSTS_SALU") / (rays / 64), 1)})
+    kr = rays_of.get(key, rays if key != "path_kernel" else None)  # (before round 3 a tail launch's rays were not split out)
+    if kr:
+        e.update({"rays": kr, "hbm_bytes_per_ray": round((f + w) / kr, 2), "valu_per_64_rays": round(g("SQ_INSTS_VALU") / (kr / 64), 1),
+                  "salu_per_64_rays": round(g("SQ_INSTS_SALU") / (kr / 64), 1)})
     e["l2_hit_rate"] = round(g("TCC_HIT_sum") / max(1.0, g("TCC_HIT_sum") + g("TCC_MISS_sum")), 3)
     if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
         e["valu_lane_utilisation"] = round(g("SQ_THREAD_CYCLES_VALU") / (g("SQ_ACTIVE_INST_VALU") * 64.0), 3)

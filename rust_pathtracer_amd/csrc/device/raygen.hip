@@ -41,8 +41,13 @@ __global__ __launch_bounds__(PT_BLOCK) void raygen_kernel(PtCamera cam, PassPara
             double xi2 = rng.f64();
             double u = ((double)x + xi1) / ((double)p.width - 1.0);  // renderer.rs:23
             double v = ((double)y + xi2) / ((double)p.height - 1.0); // renderer.rs:24
-            // camera.rs:46-56 -- the lens sample is drawn even when the aperture is 0
-            V3 rd = cam.lens_radius * random_in_unitdisk_xy(rng);
+            // camera.rs:46-56 -- the reference draws the lens sample even when the aperture is 0.  Its draws are the last of stream 0
+            // and the sample is multiplied by the lens radius: at radius 0 the offset is a vector of zeros whatever was drawn, so
+            // the rejection loop (three quarters of this kernel's instructions) is skipped -- a wave-uniform branch.  (Only the SIGN
+            // of those zeros is not reproduced; it could reach a result only through a camera origin component or an unblurred
+            // direction component that is exactly -0.0, which no difference x - x and no look-at camera produces.)
+            V3 rd = v3(0.0, 0.0, 0.0);
+            if (cam.lens_radius != 0.0) rd = cam.lens_radius * random_in_unitdisk_xy(rng);
             V3 blur_offset = c_u * rd.x + c_v * rd.y;
             V3 o = c_origin + blur_offset;
             V3 d = c_llc + u * c_hor + v * c_ver - c_origin - blur_offset;

@@ -23,7 +23,7 @@ api.libptgpu.pt_debug_read_phases(out, 1)
 ctx.accum_reset(w, h)
 st = ctx.render_accumulate(cam, w, h, (1, 1, 1), 0, spp, 50, 1)
 api.libptgpu.pt_debug_read_phases(out, 1)
-names = ["refill", "verify", "guide0", "guide1", "guide2", "guide3", "leaf", "literal"]
+names = ["refill", "finish+verify", "guide0", "guide1", "guide2", "guide3", "leaf", "literal"]
 tot_rounds = 0
 print(f"{which}: rays {st.rays}, ms {st.ms_total:.1f}")
 for i, nm in enumerate(names):
@@ -31,6 +31,6 @@ for i, nm in enumerate(names):
     print(f"  {nm:8s} rounds {r:12d}  mean active lanes {l / max(r, 1):6.2f}  lane-steps per ray {l / st.rays:6.2f}")
 g = max(1, sum(out[2 * i + 1] for i in range(2, 6)))
 print(f"  guide lane-steps {g}: no child hit {out[16] / g:.3f}, both hit {out[17] / g:.3f}; taken with a hit in hand {out[18] / g:.3f}, of those with no child hit {out[19] / max(out[18], 1):.3f}")
-tnames = ["refill", "verify", "guide", "leaf", "literal", "choose", "store"]
+tnames = ["refill", "finish+verify", "guide", "leaf", "literal", "choose", "store"]
 tot = sum(out[24 + i] for i in range(7))
 print("  wave-time by part of the loop: " + ", ".join(f"{nm} {out[24 + i] / tot:.3f}" for i, nm in enumerate(tnames)) + f"  (total {tot / 1e9:.2f} G wave-cycles)")
