@@ -101,8 +101,9 @@ __global__ void guide_refit_kernel(const DevGuideLeaf* __restrict__ leaves, cons
     for (int guard = 0; node >= 0 && guard < 128; ++guard) {
         // Release: what this thread finished below (its subtree's box, plain stores) is visible before the counter says so.
         // Acquire: the second arriver sees the first one's box (plain loads below) because it saw the first one's count.
-        if (__hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        if (__hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == 0u)
             return; // first to arrive: the other subtree is not finished, its thread goes on
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (only the second arriver reads what the first one published)
         const int2 k = kids[node];
         float box[2][6];
         uint32_t ref[2];
