@@ -814,7 +814,9 @@ struct StreamWalk {
 //      component and when the guide stack overflows.
 // Correctness never rests on the guide tree being good, only on its boxes containing their primitives.
 #define PT_GUIDE_LEAF 0x80000000u
+#ifndef PT_GUIDE_STACK /* (a build with a small stack, -DPT_GUIDE_STACK=6, sends many rays through the overflow -> literal-walk path: a test aid) */
 #define PT_GUIDE_STACK 20 /* 20 KB of LDS per block: six blocks of the tail kernel (path.hip) fit a CU; deeper => literal walk */
+#endif
 #define PT_GUIDE_STACK_SLOTS (PT_GUIDE_STACK + 1) /* levels the kernels allocate: one to spare for pt_lean.h's unconditional store */
 #define PT_GUIDE_ABS_SLACK 1e-37f /* see the box test's error budget at OrderedWalk below */
 // Wave-uniform: what the ordered walk reads.  The guide tree's allocation holds the nodes (64 bytes each, node 0 = root) and,

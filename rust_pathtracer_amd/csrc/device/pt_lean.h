@@ -16,6 +16,7 @@
 #pragma once
 #include "pt_device.h"
 
+static_assert(PT_GUIDE_STACK >= 6, "the literal walk parks the ray's three reciprocals in the first six slots of its lane's stack");
 enum { PT_LW_IDLE = 0, PT_LW_GUIDE = 1, PT_LW_LEAF = 2, PT_LW_FINISH = 3, PT_LW_VERIFY = 4, PT_LW_LITERAL = 5, PT_LW_LITERAL_BEGIN = 6 };
 
 struct LeanWalk {

@@ -420,3 +420,44 @@ def test_triangle_split_pieces_cover_the_triangle(pt):
         assert ok and 1 <= n <= 32, (tri, n)
     with pytest.raises(pt.PtError):
         pt.selftest_split_triangle(np.array([[0.0, 0, 0], [1, 0, np.nan], [0, 1, 0]]), 4)
+
+
+def test_bench_line_splits_rays_between_the_kernels_that_traced_them():
+    """bench.py's per-kernel roofline entries: PtStats.tail_from splits rays_per_bounce between the separate trace / shade launches
+    and the tail launch, and every kernel's algorithmic bytes (SURVEY.md 8(d): trace 60 B per ray; shade 76 in + 64 per survivor;
+    tail 64 in + 64 per survivor) are those of ITS rays.  Pure host arithmetic on a synthetic PtStats."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    st = api.PtStats()
+    rpb = [1000, 600, 300, 100, 40, 10, 2]
+    for b, v in enumerate(rpb):
+        st.rays_per_bounce[b] = v
+    st.rays, st.tail_from = sum(rpb), 3
+    st.ms_trace, st.ms_shade, st.ms_path = 3.0, 1.5, 2.0
+    st.ms_busy_trace, st.ms_busy_shade, st.ms_busy_path = 3.0, 1.5, 2.0
+    st.launches_trace, st.launches_shade, st.launches_path = 3, 3, 1
+    tot = bench.sum_stats([st, st])  # two render calls of one step
+    assert tot["rays_wavefront"] == 2 * 1900 and tot["survivors_wavefront"] == 2 * (600 + 300 + 100)
+    assert tot["rays_tail"] == 2 * 152 and tot["survivors_tail"] == 2 * 52 and tot["tail_from"] == 3
+    assert tot["rays_wavefront"] + tot["rays_tail"] == tot["rays"]
+    k = {e["kernel"]: e for e in bench.kernel_entries(tot, {}, 0.0, 256, 2.4e9)}
+    assert k["trace_kernel"]["rays"] == 3800 and k["trace_kernel"]["bytes_per_launch"] == 3800 * 60 // 6
+    assert k["shade_kernel"]["bytes_per_launch"] == (3800 * 76 + 2000 * 64) // 6
+    assert k["path_kernel"]["rays"] == 304 and k["path_kernel"]["bytes_per_launch"] == (304 * 64 + 104 * 64) // 2
+    for e in k.values():  # achieved = bytes / sum of launch durations; frac against 8 TB/s
+        want = e["bytes_per_launch"] * e["launches"] / (e["launch_ms_sum"] * 1e-3) / 1e9
+        assert abs(e["achieved"] - want) <= 0.01 * max(1.0, want) and abs(e["frac"] - want / 8000.0) < 1e-4
+    # no tail launch: everything belongs to trace and shade, and there is no path entry
+    st.tail_from, st.ms_path, st.launches_path = 50, 0.0, 0
+    tot = bench.sum_stats([st])
+    assert tot["rays_wavefront"] == 2052 and tot["rays_tail"] == 0
+    assert [e["kernel"] for e in bench.kernel_entries(tot, {}, 0.0, 256, 2.4e9)] == ["trace_kernel", "shade_kernel"]
+    # the issue roofline weights each kernel's instructions per ray by the rays it traced
+    pmc = {"trace_kernel": {"valu_per_64_rays": 1000.0}, "shade_kernel": {"valu_per_64_rays": 500.0}, "path_kernel": {"valu_per_64_rays": 9000.0}}
+    st.tail_from, st.ms_path, st.launches_path = 3, 2.0, 1
+    tot = bench.sum_stats([st])
+    ir = bench.issue_roofline(pmc, tot, 1000.0, 256, 2.4e9)
+    assert abs(ir["valu_per_64_segments"] - (1500.0 * 1900 + 9000.0 * 152) / 2052) < 0.1
