@@ -84,6 +84,9 @@ def parse_args():
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra untimed lanes=1 frame")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--out-image", default=None, help="write the last frame as a PNG (config 1 always writes one)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="one process per GPU: torch.distributed backend of the reduce (nccl = RCCL over xGMI).  gloo + --devices 0,0 rehearses the "
+                    "per-process code path on a box with one GPU (RCCL refuses two ranks on one device); the line then says so")
     ap.add_argument("--devices", default=None, help="comma-separated device index per worker (default 0..N-1).  Listing a device twice "
                     "rehearses the N-worker code path on a box with fewer GPUs: RCCL cannot reduce between two contexts of one device, "
                     "so the buffers are then summed through the host and the line says so")
@@ -379,18 +382,22 @@ def main():
     from rust_pathtracer_amd.distributed import render_static_sharded
 
     dist = None
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
+    if len(devices) != world:
+        raise SystemExit(f"--devices lists {len(devices)} devices for --gpus {world}")
     if per_process:
         import torch.distributed as dist
 
+        local_rank = devices[rank] if args.devices else local_rank  # (the device this rank drives)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(world))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if not per_process:
-        if len(devices) != world:
-            raise SystemExit(f"--devices lists {len(devices)} devices for --gpus {world}")
         if max(devices) >= pt.device_count():
             raise SystemExit(f"--gpus {world} needs devices {devices} but only {pt.device_count()} visible")
-    rehearsal = not per_process and len(set(devices)) < len(devices)
+    rehearsal = len(set(devices)) < len(devices)
 
     animation = bool(cfg.get("frames"))
     w, h, spp, depth = cfg["width"], cfg["height"], cfg["spp"], cfg["depth"]
@@ -536,9 +543,10 @@ def main():
             "config": {"workload": cfg["label"],
                        "parallelism": ("single GPU" if world == 1 else
                                        (f"frames mod {world}" if animation else f"spp-sharded x{world}, one RCCL reduce per frame")
-                                       + (", one process per GPU" + ("" if animation else " (torch.distributed reduce)") if per_process
+                                       + (", one process per GPU" + ("" if animation else f" (torch.distributed reduce, backend {args.dist_backend})") if per_process
                                           else ", one process, one host thread per GPU" + ("" if animation else " (pt_accum_reduce)"))
-                                       + (" -- REHEARSAL: workers share a GPU, buffers summed through the host, not a multi-GPU measurement" if rehearsal else "")),
+                                       + (" -- REHEARSAL: workers share a GPU, buffers summed through the host, not a multi-GPU measurement" if rehearsal else "")
+                                       + (" -- gloo: the reduce goes through the host, not xGMI" if per_process and args.dist_backend != "nccl" and not rehearsal else "")),
                        "rays_per_frame": rays_total // (args.steps * frames_per_step)},
             "roofline": roofline,
             "issue_roofline": issue_roofline(pmc, tot, mrays / world, n_cus, clock_hz),

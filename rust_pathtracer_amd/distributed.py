@@ -20,8 +20,20 @@ def render_static_sharded(accumulate: Callable[[int, int], None], buffer, total_
     if count > 0:
         accumulate(begin, count)
     if world_size > 1:
-        dist.reduce(buffer, dst=0, op=dist.ReduceOp.SUM)
+        reduce_to_root(buffer, dist)
     return begin, count
+
+
+def reduce_to_root(buffer, dist):
+    """Sum-reduces `buffer` to rank 0: ONE collective.  Backend "nccl" (= RCCL) reduces device tensors in place over xGMI; gloo
+    reduces host tensors only, so a device tensor goes through the host there (CPU tests, and rehearsals on a box with one GPU)."""
+    if buffer.is_cuda and dist.get_backend() == "gloo":
+        host = buffer.cpu()
+        dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+        if dist.get_rank() == 0:
+            buffer.copy_(host)
+    else:
+        dist.reduce(buffer, dst=0, op=dist.ReduceOp.SUM)
 
 
 def render_animation_sharded(render_frame: Callable[[int], object], n_frames: int, rank: int, world_size: int) -> dict:

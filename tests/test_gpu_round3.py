@@ -231,3 +231,41 @@ def test_stats_split_rays_between_the_wavefront_and_the_tail_launch(pt):
             assert out[k][0].rays == out[-1][0].rays and np.array_equal(out[k][1], out[-1][1])
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------- the driver's N > 1 command: one process per GPU under torchrun
+def test_bench_per_process_path_under_torchrun(pt, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` is how the driver runs N > 1.  On a one-GPU box both
+    ranks drive device 0 and the reduce goes through gloo (RCCL refuses two ranks on one device): everything but the collective's
+    transport is the code the 8-GPU run takes -- rank/world from the environment, sample ranges by rank, the bound torch tensor as
+    accumulation buffer, distributed.render_static_sharded, resolve on rank 0, max-over-ranks timing, one JSON line.  The frame
+    must be the single-process frame (sample s of pixel p draws the same numbers wherever it is computed)."""
+    import json
+    import sys
+
+    from test_host import read_png
+
+    w, h, spp, depth = 160, 96, 10, 12
+    out = tmp_path / "frame.png"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--dist-backend", "gloo", "--width", str(w), "--height", str(h),
+           "--spp", str(spp), "--depth", str(depth), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--out-image", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "one process per GPU" in line["config"]["parallelism"]
+    assert "REHEARSAL" in line["config"]["parallelism"]  # (two ranks on one device: labelled, never a multi-GPU number)
+    s = pt.Scene("CornellBox").set_seeds(1, 1, 1).set_image(w, h, spp, depth, (0, 0, 0)).build()
+    ctx = pt.Context(0)
+    try:
+        ctx.upload(s)
+        ctx.accum_reset(w, h)
+        st = ctx.render_accumulate(s.camera(0.0), w, h, (0, 0, 0), 0, spp, depth, 1)
+        want = ctx.resolve(spp)
+    finally:
+        ctx.close()
+    assert line["config"]["rays_per_frame"] == st.rays  # the union of the ranks' sample ranges is the whole frame
+    got = read_png(str(out))
+    assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 1  # (f32 sums in a different order)
