@@ -25,18 +25,22 @@ struct LeanWalk {
     // double and the eight bytes behind it (a triangle's seventh double) -- so that every fetch site defines the same four
     // register quads and nothing is copied after a load.
     uint4 r0, r1, r2, r3;
+    uint4 rt;             // a primitive record's bytes 64..79 (a triangle's last two doubles): fetched with the record, not after it
     uint32_t best_parent; // stream offset of the node that is the best primitive's parent in the reference's tree
     uint32_t cur;         // offset (from OrderedScene::base) of the fetched record
     uint32_t mode, sp;
     float bound;          // f32 culling bound of the box tests: near(best_t) rounded up (refreshed by step_leaf)
     pt_f32x2 q[5];        // (of.x, of.y) (of.z, invf.x) (invf.y, invf.z) (nrinv.x, nrinv.y) (nrinv.z, second_t): OrderedWalk::guide_slab
 
-    // 64 bytes at base + off: header, six doubles, and the eight bytes behind them
-    __device__ __forceinline__ void fetch(const OrderedScene& sc, uint32_t off) {
-        off = min(off, sc.fetch_limit); // (whatever the tables hold, no fetch leaves the allocation: it is padded by 128 bytes)
-        const uint4* p = reinterpret_cast<const uint4*>(sc.base + off);
+    // A step ends by aiming the lane at its next record (aim); the wave loop then loads it (load).
+    // 64 bytes at base + cur: header, six doubles, and the eight bytes behind them; a primitive record: 80
+    __device__ __forceinline__ void aim(const OrderedScene& sc, uint32_t off) {
+        cur = min(off, sc.fetch_limit); // (whatever the tables hold, no fetch leaves the allocation: it is padded by 128 bytes)
+    }
+    __device__ __forceinline__ void load(const OrderedScene& sc) {
+        const uint4* p = reinterpret_cast<const uint4*>(sc.base + cur);
         r0 = p[0]; r1 = p[1]; r2 = p[2]; r3 = p[3];
-        cur = off;
+        if (mode == PT_LW_LEAF) rt = p[4]; // (cur <= fetch_limit: inside the padding)
     }
     static __device__ __forceinline__ double f64_of(uint32_t lo, uint32_t hi) { return __hiloint2double((int)hi, (int)lo); }
     static __device__ __forceinline__ pt_f32x2 pair(uint32_t lo, uint32_t hi) {
@@ -54,7 +58,7 @@ struct LeanWalk {
         sp -= pop ? 1u : 0u;
         const bool leaf = (int32_t)ref < 0; // PT_GUIDE_LEAF
         mode = overflow ? (uint32_t)PT_LW_LITERAL_BEGIN : ((any || pop) ? (leaf ? (uint32_t)PT_LW_LEAF : (uint32_t)PT_LW_GUIDE) : (uint32_t)PT_LW_FINISH);
-        fetch(sc, leaf ? (ref & ~PT_GUIDE_LEAF) + sc.guide_bytes : ref << 6);
+        aim(sc, leaf ? (ref & ~PT_GUIDE_LEAF) + sc.guide_bytes : ref << 6);
     }
     __device__ __forceinline__ void refresh_bound() { bound = OrderedWalk::f32_not_below(OrderedWalk::near(w.best_t)) + PT_GUIDE_ABS_SLACK; }
     __device__ __forceinline__ void begin(const OrderedScene& sc, const OrderedBounds& B, V3 o, V3 d) {
@@ -90,7 +94,8 @@ struct LeanWalk {
         q[3].x = nrinv[0]; q[3].y = nrinv[1]; q[4].x = nrinv[2]; q[4].y = __builtin_huge_valf(); // no second candidate yet
         refresh_bound();
         mode = ordinary ? (uint32_t)PT_LW_GUIDE : (uint32_t)PT_LW_LITERAL_BEGIN;
-        fetch(sc, 0u); // the guide tree's root
+        aim(sc, 0u); // the guide tree's root
+        load(sc);
     }
     // OrderedWalk::guide_slab with the bound from the register and both acceptance conditions in one comparison:
     //   max(entry, t_min) <= min(exit, bound)   <=>   entry <= exit, entry <= bound, t_min <= exit   (and t_min <= bound, which
@@ -146,8 +151,7 @@ struct LeanWalk {
         if (kind == PT_WK_SPHERE) {
             consider(hit_sphere(g, o, d, t_min, bound_t, t), t, aux, link);
         } else if (kind == PT_WK_TRIANGLE) {
-            const double* rest = reinterpret_cast<const double*>(sc.base + cur + 64u); // (cur <= fetch_limit: inside the padding)
-            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], f64_of(r3.z, r3.w), rest[0], rest[1]};
+            const double tri[9] = {g[0], g[1], g[2], g[3], g[4], g[5], f64_of(r3.z, r3.w), f64_of(rt.x, rt.y), f64_of(rt.z, rt.w)};
             consider(hit_triangle(tri, o, d, t_min, bound_t, t), t, aux, link);
         } else if (kind == PT_WK_BOX6) {
             const double r0[5] = {g[2], g[0], g[3], g[1], g[4]}, r1[5] = {g[5], g[0], g[3], g[1], g[4]};
@@ -176,7 +180,7 @@ struct LeanWalk {
         const bool miss = w.best_prim < 0 && q[4].y == __builtin_huge_valf();
         const bool literal = !miss && !((double)q[4].y > OrderedWalk::near(w.best_t));
         mode = miss ? (uint32_t)PT_LW_IDLE : (literal ? (uint32_t)PT_LW_LITERAL_BEGIN : (uint32_t)PT_LW_VERIFY);
-        fetch(sc, sc.guide_bytes + best_parent);
+        aim(sc, sc.guide_bytes + best_parent);
     }
     // bvh.rs:18-35 on the box of P's parent node, operation for operation: OrderedWalk::step_verify
     __device__ __forceinline__ void step_verify(const OrderedBounds& B) {
@@ -206,7 +210,7 @@ struct LeanWalk {
             w.best_t = B.t_max;
             w.best_prim = -1;
             sp = 0u;                        // (from here on: the literal walk's offset into the stream)
-            fetch(sc, sc.guide_bytes);      // StreamWalk::begin: the root record
+            aim(sc, sc.guide_bytes);        // StreamWalk::begin: the root record
             mode = PT_LW_LITERAL;
             return;
         }
@@ -222,6 +226,6 @@ struct LeanWalk {
         else w.advance_leaf(stream);
         sp = w.off;
         if (w.off >= sc.stream_bytes) mode = PT_LW_IDLE;
-        fetch(sc, sc.guide_bytes + w.off); // (clamped to the padding when the walk is over)
+        aim(sc, sc.guide_bytes + w.off); // (clamped to the padding when the walk is over)
     }
 };

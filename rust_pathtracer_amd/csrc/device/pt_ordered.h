@@ -71,6 +71,7 @@ __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t*
     uint32_t mine = 0;
     const OrderedBounds B = OrderedWalk::bounds(t_min, t_max);
     LeanWalk w;
+    w.rt = make_uint4(0u, 0u, 0u, 0u);
     w.begin(sc, B, v3(0, 0, 0), v3(1, 1, 1));
     w.mode = PT_LW_IDLE;
     PT_PHASE_DECL;
@@ -103,38 +104,58 @@ __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t*
         const bool run_finish = n_finish >= PT_LW_FINISH_LANES || (n_finish != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u);
         const bool run_guide = !run_finish && n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES;
         const bool run_leaf = !run_finish && !run_guide && n_leaf != 0u && n_leaf >= n_literal;
+        const bool run_literal = !run_finish && !run_guide && !run_leaf;
         const int phase_slot = run_finish ? 1 : run_guide ? 2 : run_leaf ? 3 : 4;
         (void)phase_slot;
-        bool finished = false; // this lane's ray got its answer in this round
+        // (Tried: "thin" rounds for a wave with at most 24 rays in flight -- every lane takes one step of whatever kind it wants, one
+        // load for all of them at the end of the round, so that a lane at a primitive does not sit out the others' box steps.  Slower
+        // everywhere, 1M mesh 64 spp 34.6 -> 37.1 ms, 1 spp 3.9 -> 5.2 ms, SphereField 128 spp 85.6 -> 92.0 ms: a round then executes
+        // the code of every kind of step back to back, and a lone wave's f64 primitive test takes as long as a fetch;
+        // profiles/r03_thin_rounds_ab.txt.)
+        const uint32_t before = w.mode;
         if (run_finish) {
-            // lanes whose parent box has arrived take the proof step; lanes whose traversal just ended decide and fetch it
-            PT_PHASE_COUNT(1, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_FINISH || w.mode == PT_LW_VERIFY));
-            const uint32_t before = w.mode;
-            if (before == PT_LW_VERIFY) w.step_verify(B);
-            if (before == PT_LW_FINISH) w.step_finish(sc);
-            finished = w.mode == PT_LW_IDLE && (before == PT_LW_VERIFY || before == PT_LW_FINISH);
-        } else if (run_guide) {
+            // lanes whose parent box has arrived take the proof step; lanes whose traversal just ended decide and aim at it
+            PT_PHASE_COUNT(1, __builtin_amdgcn_ballot_w64(before == PT_LW_FINISH || before == PT_LW_VERIFY));
+            if (before == PT_LW_VERIFY) w.step_verify(B); // (ends the ray or turns it to the literal walk: nothing to load)
+            if (before == PT_LW_FINISH) {
+                w.step_finish(sc);
+                w.load(sc);
+            }
+        }
+        if (run_guide) {
             if (UNROLL_STEPS) {
 #pragma unroll
                 for (int r = 0; r < PT_ORD_NODE_STEPS; ++r) {
                     PT_PHASE_COUNT(2 + r, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_GUIDE));
-                    if (w.mode == PT_LW_GUIDE) w.step_guide(sc, stack, B);
+                    if (w.mode == PT_LW_GUIDE) {
+                        w.step_guide(sc, stack, B);
+                        w.load(sc);
+                    }
                 }
             } else {
 #pragma nounroll
                 for (int r = 0; r < PT_ORD_NODE_STEPS; ++r)
-                    if (w.mode == PT_LW_GUIDE) w.step_guide(sc, stack, B);
-            }
-        } else if (run_leaf) {
-            PT_PHASE_COUNT(6, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_LEAF));
-            if (w.mode == PT_LW_LEAF) w.step_leaf(sc, stack, B);
-        } else {
-            PT_PHASE_COUNT(7, __builtin_amdgcn_ballot_w64(w.mode >= PT_LW_LITERAL));
-            if (w.mode >= PT_LW_LITERAL) { // rare: one step per round keeps the kernel small
-                w.step_literal(sc, stack, B);
-                finished = w.mode == PT_LW_IDLE;
+                    if (w.mode == PT_LW_GUIDE) {
+                        w.step_guide(sc, stack, B);
+                        w.load(sc);
+                    }
             }
         }
+        if (run_leaf) {
+            PT_PHASE_COUNT(6, __builtin_amdgcn_ballot_w64(before == PT_LW_LEAF));
+            if (before == PT_LW_LEAF) {
+                w.step_leaf(sc, stack, B);
+                w.load(sc);
+            }
+        }
+        if (run_literal) {
+            PT_PHASE_COUNT(7, __builtin_amdgcn_ballot_w64(before >= PT_LW_LITERAL));
+            if (before >= PT_LW_LITERAL) { // rare: one step per round keeps the kernel small
+                w.step_literal(sc, stack, B);
+                w.load(sc);
+            }
+        }
+        const bool finished = w.mode == PT_LW_IDLE && before != PT_LW_IDLE; // this lane's ray got its answer in this round
         PT_PHASE_CLOCK(c_stepped);
         PT_PHASE_TIME(phase_slot, c_chosen, c_stepped);
         if (finished) io.store(mine, w.w.o, w.w.d, w.w.best_t, w.w.best_prim);
