@@ -164,7 +164,7 @@ const char* pt_last_error(const PtContext* ctx);
  * "repack_every" / "repack_first" (re-deal surviving rays over the waves every N bounces from bounce F on;
  *   default 0 = never / 8),
  * "lanes" (1..8: split every pass into that many sub-passes on separate HIP streams, one pipeline step apart, so one's
- *   trace overlaps another's shade; default 0 = automatic: 3), "lane_sync" (1 = lanes advance in lock step through events; default 0
+ *   trace overlaps another's shade; default 0 = automatic: 4 for scenes on the ordered walk, 3 otherwise), "lane_sync" (1 = lanes advance in lock step through events; default 0
  *   = free-running), "lane_full_grid" (1 = every lane launches the whole persistent grid, 0 = its share of it; default 0),
  * "fused" (1 = scenes that take the lockstep walk and have only solid textures run the whole bounce loop of a sub-pass in one
  *   launch, each wave on its own region; 0 = one trace and one shade launch per bounce; default 0 -- the fused kernel needs 87
@@ -183,11 +183,12 @@ const char* pt_last_error(const PtContext* ctx);
  *   (7 ms of kernels for a million triangles: for worlds rebuilt every frame); results are identical either way),
  * "tail_deal" (1, the default: the rays that enter that one launch are first dealt out over the waves one at a time -- the long-lived
  *   paths of a frame sit in a few image tiles, so in a few waves, and a tail wave's cost per bounce is that of its slowest ray; 0 = each
- *   wave keeps its own) and "tail_waves_div" (dealt over 1 / this many of the waves; default 1),
+ *   wave keeps its own) and "tail_waves_div" (dealt over 1 / this many of the waves; default 2),
  * "guide_split" (guide tree, at the next pt_scene_upload: a triangle whose box is more than this many times its own projected areas is
  *   referenced once per PIECE, cut by axis-aligned planes, at most 32 pieces and n_prims / 2 extra references per scene -- the
  *   slivers around the pole of a latitude-longitude mesh; default 4, 0 = never; results are identical),
- * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic). */
+ * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic: 8, or 6 for procedural textures off the
+ *   ordered walk). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
 
 /* Replaces scene.get_world()'s result (scene.rs:38-42): validates and uploads the flattened world.

@@ -87,7 +87,7 @@ struct PtContext {
     int blocks_per_cu_override = 0;
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
     int guide_split_ratio = 4;    // guide tree: a triangle whose box exceeds this many times its own projected areas is referenced per piece; 0 = never
-    int tail_waves_div = 1;       // ... over n_waves / this many of them
+    int tail_waves_div = 2;       // ... over n_waves / this many of them (half: 1M mesh 64 spp 34.1 -> 32.9 ms; a third or a quarter: slower)
     int tail_deal = 1;            // the rays that enter the per-wave tail launch are first dealt out evenly over the waves
     int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
     unsigned char* scratch_ptr = nullptr; // this device's address of `scratch` (hipGetSymbolAddress at context creation)
@@ -850,7 +850,9 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     g.trace_lds_bytes = (size_t)sc.lds_nodes * sizeof(DevNode) + (size_t)sc.lds_prims * sizeof(DevPrim) + stack_bytes;
     // Waves per CU of the persistent grid: 32 (8 per SIMD) when every kernel of the pass fits 8 waves per SIMD (small
     // scene, solid textures); otherwise 24, a whole number of rounds for kernels that fit 6, 3 or 2 (no ragged last round).
-    uint32_t blocks_per_cu = (sc.trace_mode != PT_TRACE_STACK && sc.trace_mode != PT_TRACE_ORDERED && !sc.has_procedural) ? 8u : 6u;
+    // (the ordered walk: 32 as well, with four lanes (pt_render_accumulate) -- SphereField 1080p 128 spp 85.3 -> 83.6 ms, the 1M mesh
+    // unchanged; profiles/r03_lanes_blocks_sweep.txt)
+    uint32_t blocks_per_cu = (sc.trace_mode == PT_TRACE_ORDERED || (sc.trace_mode != PT_TRACE_STACK && !sc.has_procedural)) ? 8u : 6u;
     if (ctx->blocks_per_cu_override > 0) blocks_per_cu = (uint32_t)ctx->blocks_per_cu_override;
     g.grid = (uint32_t)ctx->cu_count * blocks_per_cu;
     ctx->has_scene = true;
@@ -979,7 +981,7 @@ int pt_render_accumulate(PtContext* ctx, const PtCamera* camera, uint32_t width,
         // ms/frame at 32 / 64 / 128 / 256 spp: 20.5 / 37.3 / 70.4 / 133.3; two lanes on the full grid each: 21.0 / 38.0 / 72.4 /
         // 138; four lanes on a quarter each: 20.8 / 37.5 / 70.4 / 133.7; four on the full grid: 22.2 / 38.9 / 73.7 / 136-141)
         uint32_t want = (uint32_t)ctx->n_lanes;
-        if (want == 0) want = 3u;
+        if (want == 0) want = ctx->sc.trace_mode == PT_TRACE_ORDERED ? 4u : 3u; // (ordered walk: four on a quarter each, see pt_scene_upload)
         n_lanes = (int)std::min<uint32_t>(want, slots);
         geom = ctx->geom;
         if (n_lanes > 1 && !ctx->lane_full_grid) geom.grid = std::max<uint32_t>(1u, ctx->geom.grid / (uint32_t)n_lanes);
