@@ -59,8 +59,8 @@
 // Larger scenes, ordered: nearest-first over the guide tree, then the proof that the reference's walk agrees (pt_device.h).  Same
 // refill scheme as trace_stream_kernel; a lane's pending far children wait on a stack in LDS laid out [level][thread].  The wave
 // runs ONE kind of step per round -- hand out rays, box tests (PT_ORD_NODE_STEPS in a row), primitive tests, end-of-traversal
-// decisions + proof steps, or the literal walk -- chosen from how many lanes want which; every step ends by issuing the lane's
-// next fetch, so lanes that sit out a round are waiting for memory anyway.
+// decisions + proof steps, or the literal walk -- chosen from how many lanes want which; every step is followed by the loads of the
+// lane's next record, so lanes that sit out a round are waiting for memory anyway.
 // `io` supplies ray k of this wave's n rays and takes its result: the render kernel's region of the ray stream, or a slice of the
 // caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
 // UNROLL_STEPS: the box steps of a round as straight-line code (the trace kernels: SphereField 32 spp 25.6 against 26.3 ms) or as a
