@@ -245,9 +245,14 @@ def test_bench_per_process_path_under_torchrun(pt, tmp_path):
 
     from test_host import read_png
 
+    import socket
+
     w, h, spp, depth = 160, 96, 10, 12
     out = tmp_path / "frame.png"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+    with socket.socket() as probe:  # a rendezvous port nobody holds
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--dist-backend", "gloo", "--width", str(w), "--height", str(h),
            "--spp", str(spp), "--depth", str(depth), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--out-image", str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
