@@ -158,7 +158,7 @@ void tail_kernel(DevScene sc, TailArgs a) {
         const uint4* state_in = odd ? a.state[1] : a.state[0];
         uint4* state_out = odd ? a.state[0] : a.state[1];
         RegionRayIo io{in, a.hit_t, a.hit_prim, region_base};
-        ordered_wave_loop<false>(a.os, s_stack + threadIdx.x, n, 0.001, __builtin_huge_val(), io); // ray.rs:25
+        ordered_wave_loop<false, true>(a.os, s_stack + threadIdx.x, n, 0.001, __builtin_huge_val(), io); // ray.rs:25
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // the wave's hits before it reads them back
         uint32_t out_n = 0;
         for (uint32_t first = 0; first < n; first += 64u) {

@@ -269,6 +269,7 @@ struct DevScene {
     const unsigned char* guide; // the guide tree of the ordered walk (guide_tree.h), node 0 = root, followed by a copy of the record
                                 // stream (one allocation: OrderedScene); null when there is none
     uint32_t guide_nodes;
+    uint32_t deep_tree; // PT_TAIL_MIN_PRIMS primitives or more: the tail launch by default, and the wave loop's thresholds for thin waves (pt_ordered.h)
     // which rays the ordered walk may take (computed at upload from the primitives' sizes, see pt_scene_upload):
     double ow_origin_limit; // |o|inf at most this ...
     double ow_tri_extent;   // ... and (|o|inf + ow_tri_extent) * |d|inf at most ow_od_limit

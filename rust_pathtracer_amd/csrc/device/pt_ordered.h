@@ -19,6 +19,17 @@
 #ifndef PT_LW_FINISH_LANES
 #define PT_LW_FINISH_LANES 12 /* end-of-traversal decisions and proof steps run when this many lanes wait for one */
 #endif
+// Scenes with deep trees (a million triangles: most rays leave after a few steps, a few take hundreds, so a wave is thin most of the
+// time): rays are handed out earlier, and the two waiting thresholds are FRACTIONS (of 64) of the lanes that hold a ray, not lane counts.
+#ifndef PT_ORD_DEEP_REFILL_LANES
+#define PT_ORD_DEEP_REFILL_LANES 32
+#endif
+#ifndef PT_ORD_DEEP_LEAF_LANES
+#define PT_ORD_DEEP_LEAF_LANES 16
+#endif
+#ifndef PT_ORD_DEEP_FINISH_LANES
+#define PT_ORD_DEEP_FINISH_LANES 12
+#endif
 #ifdef PT_DEBUG_PHASES /* debugging aid: rounds and active lanes per kind of step, summed over all waves (read with pt_debug_read_phases) */
 #ifdef PT_DEBUG_PHASES_TIME_ONLY /* (the counters' atomics would be most of what the clocks see) */
 #define PT_PHASE_COUNT(slot, active_mask) do {} while (0)
@@ -65,7 +76,7 @@
 // caller's arrays in the parity entry (the same loop, so the parity tests exercise the refill and the phases).
 // UNROLL_STEPS: the box steps of a round as straight-line code (the trace kernels: SphereField 32 spp 25.6 against 26.3 ms) or as a
 // loop (the tail kernel, which also carries the shading code: fewer spilled values, 1M mesh 16 spp tail 7.8 -> 6.8 ms).
-template <bool UNROLL_STEPS, class RayIo>
+template <bool UNROLL_STEPS, bool DEEP, class RayIo>
 __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
     uint32_t next = 0; // first ray not yet handed to a lane (wave-uniform)
     uint32_t mine = 0;
@@ -79,7 +90,7 @@ __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t*
         PT_PHASE_CLOCK(c_top);
         const unsigned long long idle = __builtin_amdgcn_ballot_w64(w.mode == PT_LW_IDLE);
         const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (next < n && n_idle >= PT_ORD_REFILL_LANES) {
+        if (next < n && n_idle >= (DEEP ? PT_ORD_DEEP_REFILL_LANES : PT_ORD_REFILL_LANES)) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             const uint32_t k = next + rank;
             PT_PHASE_COUNT(0, __builtin_amdgcn_ballot_w64(w.mode == PT_LW_IDLE && k < n));
@@ -101,8 +112,14 @@ __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t*
         const uint32_t n_literal = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(w.mode >= PT_LW_LITERAL));
         PT_PHASE_CLOCK(c_chosen);
         PT_PHASE_TIME(5, c_refilled, c_chosen);
-        const bool run_finish = n_finish >= PT_LW_FINISH_LANES || (n_finish != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u);
-        const bool run_guide = !run_finish && n_guide != 0u && n_leaf < PT_ORD_LEAF_LANES && n_literal < PT_ORD_LEAF_LANES;
+        uint32_t leaf_lanes = PT_ORD_LEAF_LANES, finish_lanes = PT_LW_FINISH_LANES;
+        if (DEEP) {
+            const uint32_t n_busy = n_guide + n_leaf + n_finish + n_literal;
+            leaf_lanes = max(1u, (n_busy * PT_ORD_DEEP_LEAF_LANES) >> 6);
+            finish_lanes = max(1u, (n_busy * PT_ORD_DEEP_FINISH_LANES) >> 6);
+        }
+        const bool run_finish = n_finish >= finish_lanes || (n_finish != 0u && n_guide == 0u && n_leaf == 0u && n_literal == 0u);
+        const bool run_guide = !run_finish && n_guide != 0u && n_leaf < leaf_lanes && n_literal < leaf_lanes;
         const bool run_leaf = !run_finish && !run_guide && n_leaf != 0u && n_leaf >= n_literal;
         const bool run_literal = !run_finish && !run_guide && !run_leaf;
         const int phase_slot = run_finish ? 1 : run_guide ? 2 : run_leaf ? 3 : 4;
@@ -165,9 +182,9 @@ __device__ __forceinline__ void lean_wave_loop(const OrderedScene& sc, uint32_t*
     PT_PHASE_FLUSH;
 }
 
-template <bool UNROLL_STEPS = true, class RayIo>
+template <bool UNROLL_STEPS = true, bool DEEP = false, class RayIo>
 __device__ __forceinline__ void ordered_wave_loop(const OrderedScene& sc, uint32_t* stack, uint32_t n, double t_min, double t_max, RayIo& io) {
-    lean_wave_loop<UNROLL_STEPS>(sc, stack, n, t_min, t_max, io);
+    lean_wave_loop<UNROLL_STEPS, DEEP>(sc, stack, n, t_min, t_max, io);
 }
 
 struct RegionRayIo { // the wave's region of the wavefront ray stream

@@ -88,6 +88,7 @@ struct PtContext {
     int trace_mode_override = -1; // PT_TRACE_* or -1 = by scene size
     int guide_split_ratio = 4;    // guide tree: a triangle whose box exceeds this many times its own projected areas is referenced per piece; 0 = never
     int tail_waves_div = 2;       // ... over n_waves / this many of them (half: 1M mesh 64 spp 34.1 -> 32.9 ms; a third or a quarter: slower)
+    int deep_tree = -1;           // ordered walk's wave loop: thresholds for thin waves (next upload); -1 = by scene size
     int tail_deal = 1;            // the rays that enter the per-wave tail launch are first dealt out evenly over the waves
     int tail_from = -1;           // first bounce of the per-wave tail launch (ordered walk); -1 = automatic, >= max_bounces = never
     unsigned char* scratch_ptr = nullptr; // this device's address of `scratch` (hipGetSymbolAddress at context creation)
@@ -397,6 +398,9 @@ int pt_context_set_option(PtContext* ctx, const char* key, int64_t value) {
     } else if (k == "tail_waves_div") {
         if (value < 1 || value > 64) return ctx->fail(PT_ERR_BAD_ARG, "tail_waves_div out of range [1, 64]");
         ctx->tail_waves_div = (int)value;
+    } else if (k == "deep_tree") {
+        if (value < -1 || value > 1) return ctx->fail(PT_ERR_BAD_ARG, "deep_tree must be -1 (by scene size), 0 or 1");
+        ctx->deep_tree = (int)value;
     } else if (k == "tail_deal") {
         if (value < 0 || value > 1) return ctx->fail(PT_ERR_BAD_ARG, "tail_deal must be 0 or 1");
         ctx->tail_deal = (int)value;
@@ -816,6 +820,7 @@ int pt_scene_upload(PtContext* ctx, const PtSceneDesc* s) {
     // and, beyond that, in nearest-first order over the guide tree where one could be built
     sc.guide = has_guide ? (const unsigned char*)ctx->d_guide.p : nullptr;
     sc.guide_nodes = has_guide ? (uint32_t)n_guide_nodes : 0u;
+    sc.deep_tree = ctx->deep_tree >= 0 ? (uint32_t)ctx->deep_tree : (s->n_prims >= PT_TAIL_MIN_PRIMS ? 1u : 0u);
     sc.trace_mode = !large ? PT_TRACE_LOCKSTEP : (has_guide ? PT_TRACE_ORDERED : PT_TRACE_STREAM);
     if (ctx->trace_mode_override >= 0) sc.trace_mode = (uint32_t)ctx->trace_mode_override;
     if (sc.trace_mode == PT_TRACE_ORDERED && !has_guide) sc.trace_mode = PT_TRACE_STREAM; // e.g. non-finite primitive bounds

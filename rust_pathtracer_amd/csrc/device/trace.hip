@@ -136,20 +136,26 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_stream_kernel(const unsigned c
 #ifndef PT_ORDERED_WAVES
 #define PT_ORDERED_WAVES 5
 #endif
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_ORDERED_WAVES))) void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts,
-                                                                 uint32_t n_waves, double* __restrict__ hit_t, int32_t* __restrict__ hit_prim) {
+template <bool DEEP> // (pt_ordered.h: the wave loop's thresholds for scenes with deep trees)
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_ORDERED_WAVES)))
+void trace_ordered_kernel(OrderedScene sc, RayStream rays, const uint32_t* __restrict__ counts, uint32_t n_waves, double* __restrict__ hit_t,
+                          int32_t* __restrict__ hit_prim) {
     __shared__ uint32_t s_stack[PT_GUIDE_STACK_SLOTS * PT_BLOCK];
     const uint32_t wave = blockIdx.x * (blockDim.x / PT_WAVE) + (threadIdx.x >> 6);
     const uint32_t n = __builtin_amdgcn_readfirstlane(counts[wave]);
     RegionRayIo io{rays, hit_t, hit_prim, (size_t)wave * counts[n_waves]};
-    ordered_wave_loop(sc, s_stack + threadIdx.x, n, 0.001, __builtin_huge_val(), io); // ray.rs:25
+    ordered_wave_loop<true, DEEP>(sc, s_stack + threadIdx.x, n, 0.001, __builtin_huge_val(), io); // ray.rs:25
 }
 
 void launch_trace(hipStream_t s, const LaunchGeom& g, const DevScene& sc, const Wavefront& wf, const BounceIO& io) {
     const RayStream& in = wf.rays[io.in];
     if (sc.trace_mode == PT_TRACE_ORDERED) {
-        hipLaunchKernelGGL(trace_ordered_kernel, dim3(g.grid), dim3(PT_BLOCK), 0, s, ordered_scene(sc), in,
-                           io.counts_in, wf.n_waves, wf.hit_t, wf.hit_prim);
+        if (sc.deep_tree)
+            hipLaunchKernelGGL(trace_ordered_kernel<true>, dim3(g.grid), dim3(PT_BLOCK), 0, s, ordered_scene(sc), in, io.counts_in, wf.n_waves,
+                               wf.hit_t, wf.hit_prim);
+        else
+            hipLaunchKernelGGL(trace_ordered_kernel<false>, dim3(g.grid), dim3(PT_BLOCK), 0, s, ordered_scene(sc), in, io.counts_in, wf.n_waves,
+                               wf.hit_t, wf.hit_prim);
         return;
     }
     if (sc.trace_mode == PT_TRACE_STREAM) {
