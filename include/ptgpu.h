@@ -187,6 +187,9 @@ const char* pt_last_error(const PtContext* ctx);
  * "guide_split" (guide tree, at the next pt_scene_upload: a triangle whose box is more than this many times its own projected areas is
  *   referenced once per PIECE, cut by axis-aligned planes, at most 32 pieces and n_prims / 2 extra references per scene -- the
  *   slivers around the pole of a latitude-longitude mesh; default 4, 0 = never; results are identical),
+ * "deep_tree" (ordered walk, at the next pt_scene_upload: 1 = the wave loop hands out rays earlier and scales its waiting thresholds with
+ *   the lanes that hold a ray -- for trees in which most rays leave after a few steps and a few take hundreds; -1, the default = for
+ *   scenes of 65536 primitives or more; results are identical),
  * "blocks_per_cu" (persistent-grid size, applied at the next pt_scene_upload; 0 = automatic: 8, or 6 for procedural textures off the
  *   ordered walk). */
 int pt_context_set_option(PtContext* ctx, const char* key, int64_t value);
