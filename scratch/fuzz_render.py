@@ -18,6 +18,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         ctx.set_option("trace_mode", mode)
         ctx.set_option("tail_from", int(rng.choice([-1, 0, 2, 5, 4096])))
         ctx.set_option("lanes", int(rng.integers(1, 4)))
+        ctx.set_option("deep_tree", int(rng.integers(-1, 2)))
         ctx.upload(s)
         ctx.accum_reset(w, h)
         st = ctx.render_accumulate(cam, w, h, bg, 0, spp, depth, seed)

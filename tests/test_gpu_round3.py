@@ -274,3 +274,34 @@ def test_bench_per_process_path_under_torchrun(pt, tmp_path):
     assert line["config"]["rays_per_frame"] == st.rays  # the union of the ranks' sample ranges is the whole frame
     got = read_png(str(out))
     assert got.shape == want.shape and np.abs(got.astype(int) - want.astype(int)).max() <= 1  # (f32 sums in a different order)
+
+
+def test_thin_wave_thresholds_do_not_change_results(pt, oracle):
+    """Option deep_tree picks the wave loop's thresholds of the ordered walk (pt_ordered.h: fixed lane counts, or rays handed out
+    earlier and waiting thresholds scaled with the lanes that hold a ray; automatic: by scene size).  They only decide WHEN a lane
+    takes its next step: on a random world with a mesh -- wavefront bounces on the trace kernel, the rest in the tail launch -- hits
+    are the oracle's bit for bit, the ray count is the oracle's, the f32 sums are within 1e-4 of its f64 ones, and the accumulation
+    buffer is the same to the bit either way."""
+    w, h, spp, depth, bg = 64, 40, 4, 16, (0.6, 0.7, 0.9)
+    s, o = su.random_world(31, n_objects=60, with_mesh=True, extent=10.0)
+    camera = pt.camera_new((13, 2, 3), (0, 0, 0), (0, 1, 0), 40.0, w / h, 0.0, 10.0)
+    want, want_rays = o.render_accumulate(camera.as_array(), w, h, bg, 0, spp, depth, 5)
+    ro, rd = su.random_rays(77, 20000)
+    prim, t, normal, front = o.trace(ro, rd)
+    ctx = pt.Context(0)
+    try:
+        ctx.set_option("trace_mode", 3)
+        ctx.set_option("tail_from", 3)
+        out = []
+        for deep in (0, 1):
+            ctx.set_option("deep_tree", deep)
+            ctx.upload(s)
+            assert_hits_equal(ctx.trace_batch(ro, rd), prim, t, normal, front)
+            ctx.accum_reset(w, h)
+            st = ctx.render_accumulate(camera, w, h, bg, 0, spp, depth, 5)
+            out.append((st.rays, [int(x) for x in st.rays_per_bounce], ctx.accum_download()))
+        assert out[0][0] == out[1][0] and out[0][1] == out[1][1] and np.array_equal(out[0][2], out[1][2])
+        assert out[0][0] == want_rays and want_rays > w * h * spp  # (paths do bounce)
+        np.testing.assert_allclose(out[0][2], want, rtol=1e-4, atol=1e-4)
+    finally:
+        ctx.close()
