@@ -629,10 +629,16 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
         // one definition point per iteration for the per-lane state: keeps each in a single register across the
         // dispatch below instead of a web of copies at every join
         asm volatile("" : "+v"(best_t), "+v"(best_prim), "+v"(skip_until));
+        const double* gw = reinterpret_cast<const double*>(walk + off + 8u);
         const uint32_t* hdr = reinterpret_cast<const uint32_t*>(walk + off); // scalar fetches: the record feeds the VALU from SGPRs
-        const double* g = reinterpret_cast<const double*>(walk + off + 8u);
         const uint32_t kind = hdr[0];
         const uint32_t aux = hdr[1];
+        // header and the first 48 bytes of payload in one go (the stream is padded): ONE scalar-cache latency per record instead of
+        // header -> branch on the kind -> payload: Cornell frame 135.5 -> 134.1 ms, LightTest 4K 128 spp 104.3 -> 102.8 ms.  (A
+        // triangle's last three doubles follow inside its branch.  Fetching the NEXT record one iteration ahead as well: 137.7 and
+        // 105.3 ms -- the second register set's moves cost more than the hidden latency; profiles/r03_walk_record_fetch_ab.txt.)
+        const double g[6] = {gw[0], gw[1], gw[2], gw[3], gw[4], gw[5]};
+        asm volatile("" ::"s"(kind), "s"(g[0]), "s"(g[1]), "s"(g[2]), "s"(g[3]), "s"(g[4]), "s"(g[5]));
         const LaneMask act = lanes_where(skip_until <= off);
         if (kind == PT_WK_NODE) {
             const LaneMask miss = PROVEN ? walk_aabb_miss_finite(g, o, inv, t_min, best_t) : walk_aabb_miss(g, o, inv, t_min, best_t);
@@ -661,7 +667,7 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
         } else {
             if (act) {
                 double t = 0.0;
-                const LaneMask h = (kind == PT_WK_SPHERE) ? walk_sphere(g, act, o, d, t_min, best_t, t) : walk_triangle(g, act, o, d, t_min, best_t, t);
+                const LaneMask h = (kind == PT_WK_SPHERE) ? walk_sphere(g, act, o, d, t_min, best_t, t) : walk_triangle(gw, act, o, d, t_min, best_t, t);
                 if (lane_in(h)) {
                     best_t = t;
                     best_prim = (int32_t)aux;
