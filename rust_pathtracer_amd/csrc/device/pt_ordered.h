@@ -6,7 +6,8 @@
 
 // Thresholds of the loop.  Measured on SphereField (1080p, 32 spp) in round 1: handing out rays when 40 lanes are idle, primitive
 // tests when 16 lanes wait for one, four box tests per round: 26.9 ms of trace per frame (16 / 24 / 4, the stream walk's
-// values: 29.7 ms); swept again in round 3 on the lean steps (profiles/r03_lean_walk_thresholds.txt): everything within 3 %.
+// values: 29.7 ms); swept again in round 3 on the lean steps (profiles/r03_lean_walk_thresholds.txt) and on the aim + load loop
+// (r03_wave_loop_thresholds_deep.txt): SphereField within 1.5 % everywhere; the million-triangle mesh is another matter (below).
 #ifndef PT_ORD_REFILL_LANES
 #define PT_ORD_REFILL_LANES 40
 #endif
@@ -20,7 +21,10 @@
 #define PT_LW_FINISH_LANES 12 /* end-of-traversal decisions and proof steps run when this many lanes wait for one */
 #endif
 // Scenes with deep trees (a million triangles: most rays leave after a few steps, a few take hundreds, so a wave is thin most of the
-// time): rays are handed out earlier, and the two waiting thresholds are FRACTIONS (of 64) of the lanes that hold a ray, not lane counts.
+// time): rays are handed out earlier, and the two waiting thresholds are FRACTIONS (of 64) of the lanes that hold a ray, not lane counts:
+// 33.0 -> 30.1 ms per 64-spp frame of the mesh (SphereField on these: 83.9 -> 87.2 ms, so they are picked per scene: DevScene::deep_tree,
+// and used by every tail launch, whose waves are thin by construction).  Compile-time on purpose: as run-time kernel arguments the
+// same thresholds made the register allocator spill 113 values.
 #ifndef PT_ORD_DEEP_REFILL_LANES
 #define PT_ORD_DEEP_REFILL_LANES 32
 #endif
