@@ -634,9 +634,10 @@ __device__ __forceinline__ void traverse_walk_loop(const unsigned char* __restri
         const uint32_t kind = hdr[0];
         const uint32_t aux = hdr[1];
         // header and the first 48 bytes of payload in one go (the stream is padded): ONE scalar-cache latency per record instead of
-        // header -> branch on the kind -> payload: Cornell frame 135.5 -> 134.1 ms, LightTest 4K 128 spp 104.3 -> 102.8 ms.  (A
-        // triangle's last three doubles follow inside its branch.  Fetching the NEXT record one iteration ahead as well: 137.7 and
-        // 105.3 ms -- the second register set's moves cost more than the hidden latency; profiles/r03_walk_record_fetch_ab.txt.)
+        // header -> branch on the kind -> payload.  Worth little where it was measured -- three alternating rounds on two boxes said
+        // -1.1 % on the Cornell frame, six rounds on a third 135.5 against 135.8 ms: the box's drift is larger -- but never slower.  (A
+        // triangle's last three doubles follow inside its branch.  Fetching the NEXT record one iteration ahead as well was slower,
+        // 137.7 against 134.1 ms: the second register set's moves cost more than the latency hidden; profiles/r03_walk_record_fetch_ab.txt.)
         const double g[6] = {gw[0], gw[1], gw[2], gw[3], gw[4], gw[5]};
         asm volatile("" ::"s"(kind), "s"(g[0]), "s"(g[1]), "s"(g[2]), "s"(g[3]), "s"(g[4]), "s"(g[5]));
         const LaneMask act = lanes_where(skip_until <= off);
